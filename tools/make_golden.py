@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions.
+
+Runs only in the build container (needs /root/reference).  The reference's run_sr.py
+scripts are loaded by path with importlib -- nothing is copied -- and fed seeded
+synthetic inputs (sr_mi355x.synth) and crops of the reference's committed real inputs.
+Only arrays (inputs + expected outputs) are written; no reference source travels.
+
+    python tools/make_golden.py            # writes tests/golden/
+"""
+import contextlib
+import glob
+import importlib.util
+import io
+import json
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("SR_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "enph459-super-resolution_amd"))
+from sr_mi355x import synth  # noqa: E402
+
+
+def load_ref(exp):
+    spec = importlib.util.spec_from_file_location(f"ref_{exp}", os.path.join(REF, exp, "run_sr.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_lr(ref, truth, psf, shifts, f, seed):
+    clean = np.stack([ref.forward_model(truth, psf, s, f) for s in shifts])
+    return synth.sensor_frames(clean, seed=seed)
+
+
+def ibp_trace(ref, lr, shifts, psf, init, f, its, step=0.5):
+    out = {}
+    for n in its:
+        hr, errs = quiet(ref.ibp, list(lr), shifts, psf, init.copy(), factor=f, n_iter=n, step=step)
+        out[n] = hr
+    return out, np.asarray(errs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mono = load_ref("mono_cal_target")
+    rgb = load_ref("rgb_cal_target")
+    psf_g = quiet(mono.make_gaussian_psf)
+    psf_m = quiet(mono.load_measured_psf, os.path.join(REF, "calibration_beam_shift", "data"))
+    meta = {"scipy": __import__("scipy").__version__, "numpy": np.__version__}
+
+    # ---------------- C1: f=2, N=4, 32x32 LR -> 64x64 -------------------------------
+    f, h, w = 2, 32, 32
+    truth = synth.truth_image(h * f, w * f)
+    nom, meas = synth.NOMINAL_4, synth.MEASURED_4
+    lr_nom = make_lr(mono, truth, psf_g, nom, f, synth.SEED_NOISE)
+    lr_meas = make_lr(mono, truth, psf_m, meas, f, synth.SEED_NOISE + 1)
+    # rep-averaged (non-integer) frames, like rgb_cal_target/run_sr.py:107-108
+    reps = np.stack([make_lr(mono, truth, psf_m, meas, f, 1000 + r) for r in range(5)])
+    lr_avg = reps.mean(axis=0)
+    d = dict(truth=truth, psf_g=psf_g, psf_m=psf_m, shifts_nom=np.array(nom), shifts_meas=np.array(meas),
+             lr_nom=lr_nom.astype(np.uint8), lr_meas=lr_meas.astype(np.uint8), lr_reps=reps.astype(np.uint8))
+    d["blur_g"] = mono.blur(truth, psf_g)
+    d["blur_m"] = mono.blur(truth, psf_m)
+    d["shift_frac_arg"] = np.array([0.9445, -0.8677])
+    d["shift_frac"] = mono.ndi_shift(truth, (0.9445, -0.8677), order=3, mode="nearest")
+    d["shift_int_arg"] = np.array([1.0, -1.0])
+    d["shift_int"] = mono.ndi_shift(truth, (1.0, -1.0), order=3, mode="nearest")
+    d["zoom2"] = mono.ndi_zoom(lr_nom[0], 2, order=3)
+    d["native2"] = mono.ndi_zoom(np.mean(list(lr_nom), axis=0), 2, order=3)
+    d["fwd_nom"] = np.stack([mono.forward_model(truth, psf_g, s, f) for s in nom])
+    d["fwd_meas"] = np.stack([mono.forward_model(truth, psf_m, s, f) for s in meas])
+    err = lr_meas - d["fwd_meas"]
+    d["bp_meas"] = np.stack([mono.back_project(e, psf_m, s, f, truth.shape) for e, s in zip(err, meas)])
+    err = lr_nom - d["fwd_nom"]
+    d["bp_nom"] = np.stack([mono.back_project(e, psf_g, s, f, truth.shape) for e, s in zip(err, nom)])
+    d["saa_nom"] = mono.shift_and_add(list(lr_nom), nom, factor=f, order=3)
+    d["saa_meas"] = mono.shift_and_add(list(lr_avg), meas, factor=f, order=3)
+    tr, errs = ibp_trace(mono, lr_nom, nom, psf_g, d["saa_nom"], f, (1, 2, 10, 80))
+    for n, hr in tr.items():
+        d[f"ibp_nom_{n}"] = hr
+    d["ibp_nom_errors"] = errs
+    tr, errs = ibp_trace(mono, lr_avg, meas, psf_m, d["saa_meas"], f, (1, 2, 10, 50))
+    for n, hr in tr.items():
+        d[f"ibp_meas_{n}"] = hr
+    d["ibp_meas_errors"] = errs
+    np.savez_compressed(os.path.join(OUT, "synth_c1.npz"), **d)
+
+    # ---------------- C2 small: f=4, 24x24 LR -> 96x96 ------------------------------
+    f, h, w = 4, 24, 24
+    truth = synth.truth_image(h * f, w * f, seed=synth.SEED_TRUTH + 1)
+    ph = synth.phase_shifts(4)
+    nom4 = synth.NOMINAL_4
+    lr16 = make_lr(mono, truth, psf_g, ph, f, synth.SEED_NOISE + 2)
+    lr4 = make_lr(mono, truth, psf_m, nom4, f, synth.SEED_NOISE + 3)
+    d = dict(truth=truth, psf_g=psf_g, psf_m=psf_m, shifts16=np.array(ph), shifts4=np.array(nom4),
+             lr16=lr16.astype(np.uint8), lr4=lr4.astype(np.uint8))
+    d["zoom4"] = mono.ndi_zoom(lr16[3], 4, order=3)
+    d["fwd16"] = np.stack([mono.forward_model(truth, psf_g, s, f) for s in ph])
+    d["saa16"] = mono.shift_and_add(list(lr16), ph, factor=f, order=3)
+    d["saa4"] = mono.shift_and_add(list(lr4), nom4, factor=f, order=3)
+    tr, errs = ibp_trace(mono, lr16, ph, psf_g, d["saa16"], f, (1, 10, 80))
+    for n, hr in tr.items():
+        d[f"ibp16_{n}"] = hr
+    d["ibp16_errors"] = errs
+    tr, errs = ibp_trace(mono, lr4, nom4, psf_m, d["saa4"], f, (1, 10, 80))
+    for n, hr in tr.items():
+        d[f"ibp4_{n}"] = hr
+    d["ibp4_errors"] = errs
+    np.savez_compressed(os.path.join(OUT, "synth_c2_small.npz"), **d)
+
+    # ---------------- C2 full patch: f=4, N=16, 64x64 LR -> 256x256 ------------------
+    f, h, w = 4, 64, 64
+    truth = synth.truth_image(h * f, w * f, seed=synth.SEED_TRUTH + 2)
+    lr16 = make_lr(mono, truth, psf_g, ph, f, synth.SEED_NOISE + 4)
+    saa = mono.shift_and_add(list(lr16), ph, factor=f, order=3)
+    hr80, errs = quiet(mono.ibp, list(lr16), ph, psf_g, saa.copy(), factor=f, n_iter=80, step=0.5)
+    np.savez_compressed(os.path.join(OUT, "synth_c2_full.npz"), truth=truth.astype(np.float32), psf_g=psf_g,
+                        shifts16=np.array(ph), lr16=lr16.astype(np.uint8), saa16=saa, ibp16_80=hr80,
+                        ibp16_errors=np.asarray(errs))
+
+    # ---------------- ragged shapes: hr_init not f * lr shape -------------------------
+    f = 2
+    truth = synth.truth_image(65, 67, seed=synth.SEED_TRUTH + 3)
+    sh = [(0.31, -0.2), (-0.5, 0.5), (0.0, 0.75)]
+    sim = np.stack([mono.forward_model(truth, psf_m, s, f) for s in sh])  # [3, 33, 34]
+    lr = synth.sensor_frames(sim, seed=5)[:, :32, :33]  # lr smaller than sim -> cropping path :199-201
+    hr10, errs = quiet(mono.ibp, list(lr), sh, psf_m, truth * 0.9, factor=f, n_iter=10, step=0.5)
+    bp = mono.back_project(lr[0] - sim[0, :32, :33], psf_m, sh[0], f, truth.shape)  # pad path :172-175
+    # a 5x3 kernel and a big shift to pin the generic paths
+    k53 = psf_m[1:6, 2:5] / psf_m[1:6, 2:5].sum()
+    np.savez_compressed(os.path.join(OUT, "ragged.npz"), truth=truth, psf_m=psf_m, shifts=np.array(sh),
+                        lr=lr.astype(np.uint8), fwd=sim, bp0=bp, hr_init=truth * 0.9, ibp_10=hr10,
+                        ibp_errors=np.asarray(errs), k53=k53, blur53=mono.blur(truth, k53),
+                        shift_big_arg=np.array([13.7, -20.25]),
+                        shift_big=mono.ndi_shift(truth, (13.7, -20.25), order=3, mode="nearest"),
+                        zoom3=mono.ndi_zoom(truth[:21, :17], 3, order=3))
+
+    # ---------------- crops of the reference's committed real inputs ------------------
+    d = {}
+    sess = glob.glob(os.path.join(REF, "mono_cal_target", "data", "*"))[0]
+    frames, shifts = quiet(mono.load_session, sess)
+    Hh, Ww = frames[0].shape
+    for name, (y0, x0) in {"tl": (0, 0), "br": (Hh - 48, Ww - 48), "mid": (700, 1000)}.items():
+        crop = [fr[y0:y0 + 48, x0:x0 + 48].copy() for fr in frames]
+        saa = mono.shift_and_add(crop, shifts, factor=2, order=3)
+        hr, errs = quiet(mono.ibp, crop, shifts, psf_g, saa.copy(), factor=2, n_iter=10, step=0.5)
+        d[f"mono_{name}_lr"] = np.stack(crop).astype(np.uint8)
+        d[f"mono_{name}_native"] = mono.ndi_zoom(np.mean(crop, axis=0), 2, order=3)
+        d[f"mono_{name}_saa"] = saa
+        d[f"mono_{name}_ibp10"] = hr
+        d[f"mono_{name}_errors"] = np.asarray(errs)
+    d["mono_shifts"] = np.array(shifts)
+    combo = glob.glob(os.path.join(REF, "rgb_cal_target", "data", "*"))[0]
+    raw = {}
+    for idx in range(4):
+        reps = sorted(glob.glob(os.path.join(combo, f"corner{idx}_rep*.png")))
+        raw[idx] = np.stack([np.array(Image.open(r)) for r in reps])  # uint8 [R, 1536, 2048]
+    frames, shifts = quiet(rgb.load_combo, combo)
+    for name, (y0, x0) in {"tr": (0, 1024 - 48), "mid": (300, 500)}.items():
+        crop = [fr[y0:y0 + 48, x0:x0 + 48].copy() for fr in frames]
+        saa = rgb.shift_and_add(crop, shifts, factor=2, order=3)
+        hr, errs = quiet(rgb.ibp, crop, shifts, psf_m, saa.copy(), factor=2, n_iter=10, step=0.5)
+        # raw Bayer crops (uint8) of every rep so the build can redo extract_red + rep mean
+        d[f"rgb_{name}_raw"] = np.stack([raw[i][:, 2 * y0:2 * y0 + 96, 2 * x0:2 * x0 + 96] for i in range(4)])
+        d[f"rgb_{name}_lr"] = np.stack(crop)
+        d[f"rgb_{name}_native"] = rgb.ndi_zoom(np.mean(crop, axis=0), 2, order=3)
+        d[f"rgb_{name}_saa"] = saa
+        d[f"rgb_{name}_ibp10"] = hr
+        d[f"rgb_{name}_errors"] = np.asarray(errs)
+    d["rgb_shifts"] = np.array(shifts)
+    d["psf_m"] = psf_m
+    d["psf_g"] = psf_g
+    np.savez_compressed(os.path.join(OUT, "real_crops.npz"), **d)
+
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as fp:
+        json.dump({"generated_by": "tools/make_golden.py", "reference": "benedikthoward/ENPH459-Super-Resolution",
+                   "functions": "mono_cal_target/run_sr.py:157-209 (+rgb_cal_target loaders) imported by path",
+                   "versions": meta,
+                   "files": sorted(os.path.basename(p) for p in glob.glob(os.path.join(OUT, "*.npz")))}, fp, indent=1)
+    for p in sorted(glob.glob(os.path.join(OUT, "*.npz"))):
+        print(f"{os.path.basename(p):24s} {os.path.getsize(p) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
