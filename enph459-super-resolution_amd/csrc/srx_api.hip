@@ -1,0 +1,436 @@
+// srx_api.hip -- C ABI of libsrx.so (include/srx.h): primitive entry points, the composed
+// (literal, per-frame) SAA / IBP built from the primitive kernels, and dispatch to the fused
+// tile path (srx_fused.hpp) when a call is eligible for it.
+#include <cstdio>
+#include <cstring>
+
+#include "srx_prims.hpp"
+#include "srx_fused.hpp"
+
+using namespace srx;
+
+static thread_local const char *g_last_path = "none";
+
+// ---------------------------------------------------------------------------------------
+// composed building blocks
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_copy_items(const T *__restrict__ in, size_t in_item_stride, size_t n,
+                                                    T *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[(size_t)blockIdx.y * n + i] = in[(size_t)blockIdx.y * in_item_stride + i];
+}
+
+template <typename T> static int copy_items(const T *in, size_t stride, int B, size_t n, T *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_items<T>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, in, stride, n, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// scipy.ndimage.shift(order 3, 'nearest') sampled at rows i*istep, cols j*istep (istep=1: the full image)
+template <typename T>
+static int shift_sampled(const T *in, int B, int H, int W, double sy, double sx, int istep, int Ho, int Wo, T *out,
+                         bool accumulate, T *pad, AxisTap<T> *ty, AxisTap<T> *tx, bool taps_ready, hipStream_t st)
+{
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    SRX_TRY(pad_edge(in, B, H, W, pad, st));
+    SRX_TRY(prefilter2d(pad, B, Hp, Wp, MODE_REFLECT, st));
+    if (!taps_ready) {
+        SRX_TRY(build_taps(ty, Ho, Hp, TAP_SHIFT, istep, -sy, st));  // scipy negates the shift: cc = i + (-s)
+        SRX_TRY(build_taps(tx, Wo, Wp, TAP_SHIFT, istep, -sx, st));
+    }
+    return interp(pad, B, Hp, Wp, ty, tx, Ho, Wo, out, accumulate, st);
+}
+
+static size_t shift_ws(int eb, int B, int H, int W)
+{
+    const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
+}
+
+template <typename T>
+static int shift_cubic(const T *in, int B, int H, int W, double sy, double sx, T *out, void *ws, size_t wsb,
+                       hipStream_t st)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0)
+        return SRX_E_INVALID;
+    Arena ar(ws, wsb);
+    T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    return shift_sampled(in, B, H, W, sy, sx, 1, H, W, out, false, pad, ty, tx, false, st);
+}
+
+// scipy.ndimage.zoom(order 3): in [B items, stride in_stride, h, w] -> out [B, Ho, Wo]
+template <typename T>
+static int zoom_into(const T *in, size_t in_stride, int B, int h, int w, int Ho, int Wo, T *out, T *coef,
+                     AxisTap<T> *ty, AxisTap<T> *tx, hipStream_t st)
+{
+    SRX_TRY(copy_items(in, in_stride, B, (size_t)h * w, coef, st));
+    SRX_TRY(prefilter2d(coef, B, h, w, MODE_MIRROR, st));
+    const double zy = Ho > 1 ? (double)(h - 1) / (double)(Ho - 1) : 1.0;
+    const double zx = Wo > 1 ? (double)(w - 1) / (double)(Wo - 1) : 1.0;
+    SRX_TRY(build_taps(ty, Ho, h, TAP_ZOOM, 1, zy, st));
+    SRX_TRY(build_taps(tx, Wo, w, TAP_ZOOM, 1, zx, st));
+    return interp(coef, B, h, w, ty, tx, Ho, Wo, out, false, st);
+}
+
+static size_t zoom_ws(int eb, int B, int h, int w, int f)
+{
+    const size_t m = (size_t)(h > w ? h : w) * f;
+    return align_up((size_t)B * h * w * eb) + 2 * align_up(m * sizeof(AxisTap<double>));
+}
+
+template <typename T>
+static int zoom_cubic(const T *in, int B, int h, int w, int f, T *out, void *ws, size_t wsb, hipStream_t st)
+{
+    if (!in || !out || B <= 0 || h <= 0 || w <= 0 || f <= 0)
+        return SRX_E_INVALID;
+    Arena ar(ws, wsb);
+    T *coef = ar.take<T>((size_t)B * h * w);
+    AxisTap<T> *ty = ar.take<AxisTap<T>>((size_t)h * f), *tx = ar.take<AxisTap<T>>((size_t)w * f);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    return zoom_into(in, (size_t)h * w, B, h, w, h * f, w * f, out, coef, ty, tx, st);
+}
+
+// forward_model = decimate(shift(blur(hr)))
+static size_t forward_ws(int eb, int B, int H, int W)
+{
+    return align_up((size_t)B * H * W * eb) + shift_ws(eb, B, H, W);
+}
+
+template <typename T>
+static int forward_model(const T *hr, int B, int H, int W, const double *k, int kh, int kw, double sy, double sx, int f,
+                         T *out, void *ws, size_t wsb, hipStream_t st)
+{
+    if (!hr || !out || !k || B <= 0 || H <= 0 || W <= 0 || f <= 0)
+        return SRX_E_INVALID;
+    Arena ar(ws, wsb);
+    T *b = ar.take<T>((size_t)B * H * W);
+    T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    const int sh = cdiv(H, f), sw = cdiv(W, f);
+    AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    SRX_TRY(blur(hr, B, H, W, k, kh, kw, false, b, st));
+    return shift_sampled(b, B, H, W, sy * f, sx * f, f, sh, sw, out, false, pad, ty, tx, false, st);
+}
+
+// back_project = blur_flipped(shift(zero_insert(err), -s f))
+static size_t backproject_ws(int eb, int B, int H, int W)
+{
+    return 2 * align_up((size_t)B * H * W * eb) + shift_ws(eb, B, H, W);
+}
+
+template <typename T>
+static int back_project(const T *err, int B, int eh, int ew, const double *k, int kh, int kw, double sy, double sx,
+                        int f, int H, int W, T *out, void *ws, size_t wsb, hipStream_t st)
+{
+    if (!err || !out || !k || B <= 0 || eh <= 0 || ew <= 0 || H <= 0 || W <= 0 || f <= 0)
+        return SRX_E_INVALID;
+    if (B > 65535)
+        return SRX_E_UNSUPPORTED;
+    Arena ar(ws, wsb);
+    T *up = ar.take<T>((size_t)B * H * W), *s2 = ar.take<T>((size_t)B * H * W);
+    T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, err, eh, ew, f, H, W, up);
+    SRX_CHECK_LAUNCH();
+    SRX_TRY(shift_sampled(up, B, H, W, -sy * f, -sx * f, 1, H, W, s2, false, pad, ty, tx, false, st));
+    return blur(s2, B, H, W, k, kh, kw, true, out, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// composed shift_and_add
+// ---------------------------------------------------------------------------------------
+static size_t saa_ws_composed(int eb, int B, int N, int h, int w, int f)
+{
+    (void)N;
+    const size_t H = (size_t)h * f, W = (size_t)w * f;
+    return align_up((size_t)B * h * w * eb) + align_up((size_t)B * H * W * eb) +
+           align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
+           4 * align_up((H > W ? H : W) * sizeof(AxisTap<double>));
+}
+
+template <typename T>
+static int saa_composed(const T *lr, int B, int N, int h, int w, const double *sh, int f, T *out, void *ws, size_t wsb,
+                        hipStream_t st)
+{
+    const int H = h * f, W = w * f;
+    Arena ar(ws, wsb);
+    T *coef = ar.take<T>((size_t)B * h * w), *up = ar.take<T>((size_t)B * H * W);
+    T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    AxisTap<T> *zy = ar.take<AxisTap<T>>(H), *zx = ar.take<AxisTap<T>>(W);
+    AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    const size_t n = (size_t)B * H * W;
+    if (hipMemsetAsync(out, 0, n * sizeof(T), st) != hipSuccess)
+        return SRX_E_HIP;
+    for (int k = 0; k < N; k++) {
+        SRX_TRY(zoom_into(lr + (size_t)k * h * w, (size_t)N * h * w, B, h, w, H, W, up, coef, zy, zx, st));
+        SRX_TRY(shift_sampled(up, B, H, W, sh[2 * k] * f, sh[2 * k + 1] * f, 1, H, W, out, true, pad, ty, tx, false,
+                              st));
+    }
+    hipLaunchKernelGGL(k_div<T>, dim3(grid1d(n)), dim3(256), 0, st, out, (T)N, n);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// composed ibp: the reference's loop, frame by frame (run_sr.py:190-209).  blur(hr) is taken
+// once per iteration (it is the same array for every frame); everything else is literal.
+// ---------------------------------------------------------------------------------------
+static size_t ibp_ws_composed(int eb, int B, int N, int h, int w, int H, int W, int f)
+{
+    (void)h;
+    (void)w;
+    const size_t P = align_up((size_t)B * H * W * eb);
+    const size_t sh = cdiv(H, f), sw = cdiv(W, f);
+    return 5 * P + align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
+           2 * align_up((size_t)B * sh * sw * eb) + (size_t)4 * N * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
+}
+
+template <typename T>
+static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *shf, const double *k, int kh, int kw,
+                        const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
+                        size_t wsb, hipStream_t st)
+{
+    const int sh = cdiv(H, f), sw = cdiv(W, f);
+    const int mh = sh < h ? sh : h, mw = sw < w ? sw : w;
+    const size_t P = (size_t)B * H * W;
+    Arena ar(ws, wsb);
+    T *b = ar.take<T>(P), *up = ar.take<T>(P), *s2 = ar.take<T>(P), *bp = ar.take<T>(P), *corr = ar.take<T>(P);
+    T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *sim = ar.take<T>((size_t)B * sh * sw), *err = ar.take<T>((size_t)B * sh * sw);
+    AxisTap<T> *taps[4 * SRX_MAX_FRAMES];
+    const size_t tl = (size_t)(H > W ? H : W);
+    for (int i = 0; i < 4 * N; i++)
+        taps[i] = ar.take<AxisTap<T>>(tl);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    for (int q = 0; q < N; q++) {
+        const double sy = shf[2 * q] * f, sx = shf[2 * q + 1] * f;
+        SRX_TRY(build_taps(taps[4 * q + 0], sh, Hp, TAP_SHIFT, f, -sy, st));
+        SRX_TRY(build_taps(taps[4 * q + 1], sw, Wp, TAP_SHIFT, f, -sx, st));
+        SRX_TRY(build_taps(taps[4 * q + 2], H, Hp, TAP_SHIFT, 1, sy, st));  // back_project shifts by -s: cc = i + s
+        SRX_TRY(build_taps(taps[4 * q + 3], W, Wp, TAP_SHIFT, 1, sx, st));
+    }
+    if (hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SRX_E_HIP;
+    if (errors && hipMemsetAsync(errors, 0, (size_t)B * n_iter * sizeof(double), st) != hipSuccess)
+        return SRX_E_HIP;
+    const double scale = 1.0 / ((double)mh * (double)mw) / (double)N;
+    for (int it = 0; it < n_iter; it++) {
+        SRX_TRY(blur(hr, B, H, W, k, kh, kw, false, b, st));
+        if (hipMemsetAsync(corr, 0, P * sizeof(T), st) != hipSuccess)
+            return SRX_E_HIP;
+        for (int q = 0; q < N; q++) {
+            SRX_TRY(shift_sampled(b, B, H, W, 0, 0, f, sh, sw, sim, false, pad, taps[4 * q], taps[4 * q + 1], true, st));
+            hipLaunchKernelGGL(k_residual<T>, dim3(cdiv(mw, 64), cdiv(mh, 4), B), dim3(64, 4), 0, st,
+                               lr + (size_t)q * h * w, (size_t)N * h * w, w, sim, (size_t)sh * sw, sw, mh, mw, err,
+                               errors ? errors + it : nullptr, n_iter, scale);
+            SRX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, err, mh, mw, f, H,
+                               W, up);
+            SRX_CHECK_LAUNCH();
+            SRX_TRY(shift_sampled(up, B, H, W, 0, 0, 1, H, W, s2, false, pad, taps[4 * q + 2], taps[4 * q + 3], true, st));
+            SRX_TRY(blur(s2, B, H, W, k, kh, kw, true, bp, st));
+            hipLaunchKernelGGL(k_add<T>, dim3(grid1d(P)), dim3(256), 0, st, corr, bp, P);
+            SRX_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(k_update<T>, dim3(grid1d(P)), dim3(256), 0, st, hr, corr, (T)step, (T)N, P);
+        SRX_CHECK_LAUNCH();
+    }
+    return SRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------
+static bool basic_ibp_args_ok(const void *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh,
+                              int kw, const void *hr_init, int H, int W, int f, int n_iter, void *hr)
+{
+    return lr && sh && k && hr_init && hr && B > 0 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && f > 0 && kh > 0 &&
+           kw > 0 && n_iter >= 0;
+}
+
+template <typename T>
+static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
+                        const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
+                        size_t wsb, hipStream_t st, unsigned flags)
+{
+    if (!basic_ibp_args_ok(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, hr))
+        return SRX_E_INVALID;
+    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || B > 65535)
+        return SRX_E_UNSUPPORTED;
+    const bool can_fuse = fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f);
+    if ((flags & SRX_FLAG_FUSED) && !can_fuse)
+        return SRX_E_UNSUPPORTED;
+    if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
+        g_last_path = "fused";
+        return fused::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
+    }
+    g_last_path = "composed";
+    return ibp_composed<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
+}
+
+template <typename T>
+static int saa_dispatch(const T *lr, int B, int N, int h, int w, const double *sh, int f, T *out, void *ws, size_t wsb,
+                        hipStream_t st, unsigned flags)
+{
+    if (!lr || !sh || !out || B <= 0 || N <= 0 || h <= 0 || w <= 0 || f <= 0)
+        return SRX_E_INVALID;
+    if (N > SRX_MAX_FRAMES || B > 65535)
+        return SRX_E_UNSUPPORTED;
+    const bool can_fuse = fused::saa_eligible(N, h, w, sh, f);
+    if ((flags & SRX_FLAG_FUSED) && !can_fuse)
+        return SRX_E_UNSUPPORTED;
+    if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
+        g_last_path = "fused";
+        return fused::saa<T>(lr, B, N, h, w, sh, f, out, ws, wsb, st);
+    }
+    g_last_path = "composed";
+    return saa_composed<T>(lr, B, N, h, w, sh, f, out, ws, wsb, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int srx_version(void) { return 100; }
+
+const char *srx_strerror(int s)
+{
+    switch (s) {
+    case SRX_OK: return "ok";
+    case SRX_E_INVALID: return "invalid argument";
+    case SRX_E_UNSUPPORTED: return "unsupported configuration";
+    case SRX_E_WORKSPACE: return "workspace missing or too small";
+    case SRX_E_HIP: return "HIP runtime error";
+    default: return "unknown status";
+    }
+}
+
+const char *srx_last_path(void) { return g_last_path; }
+
+size_t srx_shift_workspace_bytes(int eb, int B, int H, int W) { return shift_ws(eb, B, H, W); }
+size_t srx_zoom_workspace_bytes(int eb, int B, int h, int w, int f) { return zoom_ws(eb, B, h, w, f); }
+size_t srx_forward_workspace_bytes(int eb, int B, int H, int W) { return forward_ws(eb, B, H, W); }
+size_t srx_backproject_workspace_bytes(int eb, int B, int H, int W) { return backproject_ws(eb, B, H, W); }
+
+size_t srx_saa_workspace_bytes(int eb, int B, int N, int h, int w, int f)
+{
+    size_t a = saa_ws_composed(eb, B, N, h, w, f), b = fused::saa_ws(eb, B, N, h, w, f);
+    return a > b ? a : b;
+}
+
+size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W, int f, unsigned flags)
+{
+    size_t a = ibp_ws_composed(eb, B, N, h, w, H, W, f), b = fused::ibp_ws(eb, B, N, h, w, H, W, f);
+    if (flags & SRX_FLAG_FUSED)
+        return b;
+    if (flags & SRX_FLAG_COMPOSED)
+        return a;
+    return a > b ? a : b;
+}
+
+#define SRX_DEFINE(SFX, T)                                                                                             \
+    int srx_blur_##SFX(const T *img, int B, int H, int W, const double *k, int kh, int kw, T *out, srx_stream_t s)      \
+    {                                                                                                                  \
+        return blur<T>(img, B, H, W, k, kh, kw, false, out, hs(s));                                                    \
+    }                                                                                                                  \
+    int srx_shift_cubic_##SFX(const T *in, int B, int H, int W, double sy, double sx, T *out, void *ws, size_t wsb,     \
+                              srx_stream_t s)                                                                          \
+    {                                                                                                                  \
+        return shift_cubic<T>(in, B, H, W, sy, sx, out, ws, wsb, hs(s));                                               \
+    }                                                                                                                  \
+    int srx_zoom_cubic_##SFX(const T *in, int B, int h, int w, int f, T *out, void *ws, size_t wsb, srx_stream_t s)     \
+    {                                                                                                                  \
+        return zoom_cubic<T>(in, B, h, w, f, out, ws, wsb, hs(s));                                                     \
+    }                                                                                                                  \
+    int srx_forward_##SFX(const T *hr, int B, int H, int W, const double *k, int kh, int kw, double sy, double sx,      \
+                          int f, T *out, void *ws, size_t wsb, srx_stream_t s)                                         \
+    {                                                                                                                  \
+        return forward_model<T>(hr, B, H, W, k, kh, kw, sy, sx, f, out, ws, wsb, hs(s));                               \
+    }                                                                                                                  \
+    int srx_backproject_##SFX(const T *err, int B, int eh, int ew, const double *k, int kh, int kw, double sy,          \
+                              double sx, int f, int H, int W, T *out, void *ws, size_t wsb, srx_stream_t s)            \
+    {                                                                                                                  \
+        return back_project<T>(err, B, eh, ew, k, kh, kw, sy, sx, f, H, W, out, ws, wsb, hs(s));                       \
+    }                                                                                                                  \
+    int srx_saa_##SFX(const T *lr, int B, int N, int h, int w, const double *sh, int f, T *out, void *ws, size_t wsb,   \
+                      srx_stream_t s, unsigned flags)                                                                  \
+    {                                                                                                                  \
+        return saa_dispatch<T>(lr, B, N, h, w, sh, f, out, ws, wsb, hs(s), flags);                                     \
+    }                                                                                                                  \
+    int srx_ibp_##SFX(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,       \
+                      const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr_out, double *errors,       \
+                      void *ws, size_t wsb, srx_stream_t s, unsigned flags)                                            \
+    {                                                                                                                  \
+        return ibp_dispatch<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr_out, errors, ws, wsb, \
+                               hs(s), flags);                                                                          \
+    }                                                                                                                  \
+    int srx_decimate_##SFX(const T *in, int B, int H, int W, int f, int py, int px, T *out, srx_stream_t s)             \
+    {                                                                                                                  \
+        if (!in || !out || B <= 0 || f <= 0 || py < 0 || px < 0 || py >= H || px >= W)                                 \
+            return SRX_E_INVALID;                                                                                      \
+        if (B > 65535)                                                                                                 \
+            return SRX_E_UNSUPPORTED;                                                                                  \
+        const int h = cdiv(H - py, f), w = cdiv(W - px, f);                                                            \
+        hipLaunchKernelGGL(k_decimate<T>, dim3(cdiv(w, 64), cdiv(h, 4), B), dim3(64, 4), 0, hs(s), in, H, W, f, py, px, \
+                           h, w, out);                                                                                 \
+        SRX_CHECK_LAUNCH();                                                                                            \
+        return SRX_OK;                                                                                                 \
+    }                                                                                                                  \
+    int srx_zero_insert_##SFX(const T *in, int B, int eh, int ew, int f, int H, int W, T *out, srx_stream_t s)          \
+    {                                                                                                                  \
+        if (!in || !out || B <= 0 || f <= 0 || eh <= 0 || ew <= 0 || H <= 0 || W <= 0)                                 \
+            return SRX_E_INVALID;                                                                                      \
+        if (B > 65535)                                                                                                 \
+            return SRX_E_UNSUPPORTED;                                                                                  \
+        hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, hs(s), in, eh, ew, f, H, \
+                           W, out);                                                                                    \
+        SRX_CHECK_LAUNCH();                                                                                            \
+        return SRX_OK;                                                                                                 \
+    }                                                                                                                  \
+    int srx_mean_frames_##SFX(const T *in, int B, int R, size_t n, T *out, srx_stream_t s)                              \
+    {                                                                                                                  \
+        if (!in || !out || B <= 0 || R <= 0 || n == 0)                                                                 \
+            return SRX_E_INVALID;                                                                                      \
+        if (B > 65535)                                                                                                 \
+            return SRX_E_UNSUPPORTED;                                                                                  \
+        hipLaunchKernelGGL(k_mean_frames<T>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, hs(s), in, R, n, out); \
+        SRX_CHECK_LAUNCH();                                                                                            \
+        return SRX_OK;                                                                                                 \
+    }                                                                                                                  \
+    int srx_u8_to_##SFX(const uint8_t *in, size_t n, T *out, srx_stream_t s)                                            \
+    {                                                                                                                  \
+        if (!in || !out || n == 0)                                                                                     \
+            return SRX_E_INVALID;                                                                                      \
+        hipLaunchKernelGGL(k_u8_to<T>, dim3(grid1d(n)), dim3(256), 0, hs(s), in, n, out);                              \
+        SRX_CHECK_LAUNCH();                                                                                            \
+        return SRX_OK;                                                                                                 \
+    }                                                                                                                  \
+    int srx_quantize_u8_##SFX(const T *in, size_t n, uint8_t *out, srx_stream_t s)                                      \
+    {                                                                                                                  \
+        if (!in || !out || n == 0)                                                                                     \
+            return SRX_E_INVALID;                                                                                      \
+        hipLaunchKernelGGL(k_quantize_u8<T>, dim3(grid1d(n)), dim3(256), 0, hs(s), in, n, out);                        \
+        SRX_CHECK_LAUNCH();                                                                                            \
+        return SRX_OK;                                                                                                 \
+    }
+
+SRX_DEFINE(f32, float)
+SRX_DEFINE(f64, double)
+
+}  // extern "C"

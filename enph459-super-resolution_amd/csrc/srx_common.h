@@ -1,0 +1,83 @@
+// srx_common.h -- shared host/device helpers of libsrx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "srx.h"
+
+#define SRX_NPAD 12     // scipy.ndimage pre-pads 'nearest' inputs by 12 samples before the spline prefilter
+#define SRX_HORIZON 64  // z^64 ~ 1e-37: boundary sums of the prefilter are exact in float64 past this
+
+namespace srx {
+
+// cubic B-spline pole sqrt(3) - 2
+template <typename T> __host__ __device__ constexpr T pole() { return (T)-0.26794919243112270647; }
+
+template <typename T> struct AxisTap {
+    int idx[4];  // coefficient indices (boundary rule already applied)
+    T w[4];      // cubic B-spline weights (all zero = sample is cval 0)
+};
+
+template <typename T> struct KernelArg {
+    T k[SRX_MAX_KERNEL_TAPS];
+};
+
+static inline hipStream_t hs(srx_stream_t s) { return (hipStream_t)s; }
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+    char *base;
+    size_t cap, off;
+    bool ok;
+    Arena(void *p, size_t n) : base((char *)p), cap(n), off(0), ok(p != nullptr || n == 0) {}
+    template <typename U> U *take(size_t count)
+    {
+        size_t bytes = align_up(count * sizeof(U));
+        if (!ok || off + bytes > cap) {
+            ok = false;
+            return nullptr;
+        }
+        U *r = (U *)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define SRX_CHECK_LAUNCH()                       \
+    do {                                         \
+        if (hipGetLastError() != hipSuccess)     \
+            return SRX_E_HIP;                    \
+    } while (0)
+
+#define SRX_TRY(expr)                            \
+    do {                                         \
+        int _rc = (expr);                        \
+        if (_rc != SRX_OK)                       \
+            return _rc;                          \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// cubic B-spline weights for fractional offset t in [0, 1), computed as scipy does (ni_splines.c)
+__device__ __forceinline__ void bspline3_weights(double t, double w[4])
+{
+    double y = t, z = 1.0 - t;
+    w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+    w[0] = z * z * z / 6.0;
+    w[3] = 1.0 - w[0] - w[1] - w[2];
+}
+
+}  // namespace srx

@@ -1,0 +1,440 @@
+// srx_prims.hpp -- primitive HIP kernels of the SR core (general path) and their launchers.
+//
+// Each kernel is one step of what the reference does through SciPy
+// (mono_cal_target/run_sr.py:157-209): 7x7 "same" convolution, 12-px edge pre-pad, cubic
+// B-spline recursive prefilter with SciPy's exact boundary sums, 4x4-tap evaluation through
+// per-axis tap tables, the stride-f index maps and the pointwise IBP glue.  They are written
+// for generality (any shift, any kernel <= 15x15, ragged shapes) and serve (a) the
+// primitive C-ABI entry points, (b) the composed IBP/SAA path, (c) as the on-GPU cross-check
+// for the fused tile kernels in srx_fused.hpp.
+#pragma once
+#include "srx_common.h"
+
+namespace srx {
+
+// =========================================================================================
+// blur: out[i,j] = sum_{m,n} img[i+oy-m, j+ox-n] k[m,n]  (zero outside), oy=(kh-1)/2, ox=(kw-1)/2
+// =========================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) k_blur(const T *__restrict__ img, int H, int W, KernelArg<T> ka, int kh, int kw,
+                                              T *__restrict__ out)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (i >= H || j >= W)
+        return;
+    const size_t plane = (size_t)H * W;
+    const T *src = img + blockIdx.z * plane;
+    const int oy = (kh - 1) / 2, ox = (kw - 1) / 2;
+    T acc = 0;
+    for (int m = 0; m < kh; m++) {
+        const int y = i + oy - m;
+        if (y < 0 || y >= H)
+            continue;
+        for (int n = 0; n < kw; n++) {
+            const int x = j + ox - n;
+            if (x < 0 || x >= W)
+                continue;
+            acc += src[(size_t)y * W + x] * ka.k[m * kw + n];
+        }
+    }
+    out[blockIdx.z * plane + (size_t)i * W + j] = acc;
+}
+
+template <typename T>
+static int blur(const T *img, int B, int H, int W, const double *kernel, int kh, int kw, bool flip, T *out,
+                hipStream_t st)
+{
+    if (!img || !out || !kernel || B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0)
+        return SRX_E_INVALID;
+    if (kh * kw > SRX_MAX_KERNEL_TAPS || B > 65535)
+        return SRX_E_UNSUPPORTED;
+    KernelArg<T> ka;
+    for (int i = 0; i < kh * kw; i++)
+        ka.k[i] = (T)kernel[flip ? kh * kw - 1 - i : i];  // flip = kernel[::-1, ::-1]
+    dim3 blk(64, 4), grd(cdiv(W, 64), cdiv(H, 4), B);
+    hipLaunchKernelGGL(k_blur<T>, grd, blk, 0, st, img, H, W, ka, kh, kw, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// =========================================================================================
+// edge pre-pad (np.pad(mode='edge') by 12): in [B,H,W] -> out [B,H+24,W+24]
+// =========================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) k_pad_edge(const T *__restrict__ in, int H, int W, T *__restrict__ out)
+{
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y * 4 + threadIdx.y;
+    if (r >= Hp || c >= Wp)
+        return;
+    const int rr = min(max(r - SRX_NPAD, 0), H - 1);
+    const int cc = min(max(c - SRX_NPAD, 0), W - 1);
+    out[(size_t)blockIdx.z * Hp * Wp + (size_t)r * Wp + c] = in[(size_t)blockIdx.z * H * W + (size_t)rr * W + cc];
+}
+
+template <typename T> static int pad_edge(const T *in, int B, int H, int W, T *out, hipStream_t st)
+{
+    dim3 blk(64, 4), grd(cdiv(W + 2 * SRX_NPAD, 64), cdiv(H + 2 * SRX_NPAD, 4), B);
+    hipLaunchKernelGGL(k_pad_edge<T>, grd, blk, 0, st, in, H, W, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// =========================================================================================
+// cubic B-spline prefilter (scipy.ndimage.spline_filter1d, order 3), exact boundary sums.
+// mode 0 = 'mirror' (whole-sample symmetric; used by zoom), 1 = 'reflect' (half-sample; used
+// by shift(mode='nearest') on the pre-padded array).  `get(i)` returns 6 * x[i].
+// =========================================================================================
+enum { MODE_MIRROR = 0, MODE_REFLECT = 1 };
+
+template <typename T, typename F> __device__ __forceinline__ T causal_init(F get, int n, int mode)
+{
+    const T z = pole<T>();
+    if (n > SRX_HORIZON) {
+        // z^n underflows the format: the far-end terms of SciPy's sums vanish
+        T zi = 1, acc = 0;
+        for (int i = 0; i < SRX_HORIZON; i++) {
+            acc += zi * get(i);
+            zi *= z;
+        }
+        return mode == MODE_MIRROR ? acc : get(0) + z * acc;
+    }
+    if (mode == MODE_MIRROR) {
+        T zi = z;
+        const T zn1 = (T)pow((double)z, (double)(n - 1));
+        T c0 = get(0) + zn1 * get(n - 1);
+        for (int i = 1; i < n - 1; i++) {
+            c0 += (zi + zn1 * zn1 / zi) * get(i);
+            zi *= z;
+        }
+        return c0 / ((T)1 - zn1 * zn1);
+    } else {
+        T zi = z;
+        const T zn = (T)pow((double)z, (double)n);
+        const T c0 = get(0);
+        T acc = c0 + zn * get(n - 1);
+        for (int i = 1; i < n; i++) {
+            acc += zi * (get(i) + zn * get(n - 1 - i));
+            zi *= z;
+        }
+        return acc * (z / ((T)1 - zn * zn)) + c0;
+    }
+}
+
+// last coefficient from the causal-filtered values cp[n-1], cp[n-2]
+template <typename T> __device__ __forceinline__ T anticausal_init(T cp_last, T cp_prev, int mode)
+{
+    const T z = pole<T>();
+    return mode == MODE_MIRROR ? (z * cp_prev + cp_last) * z / (z * z - (T)1) : cp_last * (z / (z - (T)1));
+}
+
+// axis 0 (down the columns): one thread per (batch, column); lanes walk adjacent columns -> coalesced.
+template <typename T> __global__ void __launch_bounds__(64) k_prefilter_axis0(T *__restrict__ a, int Hc, int Wc, int mode)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= Wc || Hc <= 1)
+        return;
+    const T z = pole<T>();
+    T *col = a + (size_t)blockIdx.y * Hc * Wc + c;
+    const size_t s = Wc;
+    T prev = causal_init<T>([&](int i) { return (T)6 * col[i * s]; }, Hc, mode);
+    col[0] = prev;
+    for (int i = 1; i < Hc; i++) {
+        prev = (T)6 * col[i * s] + z * prev;
+        col[i * s] = prev;
+    }
+    T next = anticausal_init<T>(col[(size_t)(Hc - 1) * s], col[(size_t)(Hc - 2) * s], mode);
+    col[(size_t)(Hc - 1) * s] = next;
+    for (int i = Hc - 2; i >= 0; i--) {
+        next = z * (next - col[i * s]);
+        col[i * s] = next;
+    }
+}
+
+// axis 1 (along the rows): one wave per 64 rows; 64x64 tiles staged through LDS so that global
+// traffic stays coalesced while each lane runs the recursion along its own row (stride 65: no
+// bank conflicts).  Two sweeps: causal left->right, anticausal right->left.
+template <typename T> __global__ void __launch_bounds__(64) k_prefilter_axis1(T *__restrict__ a, int Hc, int Wc, int mode)
+{
+    __shared__ T tile[64][65];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 64;
+    const int rows = min(64, Hc - r0);
+    if (Wc <= 1)
+        return;
+    T *base = a + (size_t)blockIdx.y * Hc * Wc + (size_t)r0 * Wc;
+    const T z = pole<T>();
+    const int nchunk = cdiv(Wc, 64);
+    T carry = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int c0 = ch * 64, cw = min(64, Wc - c0);
+        for (int rr = 0; rr < rows; rr++)
+            if (lane < cw)
+                tile[rr][lane] = base[(size_t)rr * Wc + c0 + lane];
+        __syncthreads();
+        if (lane < rows) {
+            int j = 0;
+            if (ch == 0) {
+                // boundary sum: needs the first min(n, 64) samples (all in tile 0) -- and for n <= 64 the whole line
+                carry = causal_init<T>([&](int i) { return (T)6 * tile[lane][i]; }, Wc, mode);
+                tile[lane][0] = carry;
+                j = 1;
+            }
+            for (; j < cw; j++) {
+                carry = (T)6 * tile[lane][j] + z * carry;
+                tile[lane][j] = carry;
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < rows; rr++)
+            if (lane < cw)
+                base[(size_t)rr * Wc + c0 + lane] = tile[rr][lane];
+        __syncthreads();
+    }
+    for (int ch = nchunk - 1; ch >= 0; ch--) {
+        const int c0 = ch * 64, cw = min(64, Wc - c0);
+        for (int rr = 0; rr < rows; rr++)
+            if (lane < cw)
+                tile[rr][lane] = base[(size_t)rr * Wc + c0 + lane];
+        __syncthreads();
+        if (lane < rows) {
+            int j = cw - 1;
+            if (ch == nchunk - 1) {
+                // cp[n-2] lives in this tile unless the last chunk holds a single column
+                const T cp_prev = cw >= 2 ? tile[lane][cw - 2] : base[(size_t)lane * Wc + Wc - 2];
+                carry = anticausal_init<T>(tile[lane][cw - 1], cp_prev, mode);
+                tile[lane][cw - 1] = carry;
+                j = cw - 2;
+            }
+            for (; j >= 0; j--) {
+                carry = z * (carry - tile[lane][j]);
+                tile[lane][j] = carry;
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < rows; rr++)
+            if (lane < cw)
+                base[(size_t)rr * Wc + c0 + lane] = tile[rr][lane];
+        __syncthreads();
+    }
+}
+
+// spline_filter(order 3): axis 0 first, then axis 1 (scipy/ndimage/_interpolation.py: spline_filter)
+template <typename T> static int prefilter2d(T *a, int B, int Hc, int Wc, int mode, hipStream_t st)
+{
+    if (B > 65535)
+        return SRX_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), B), dim3(64), 0, st, a, Hc, Wc, mode);
+    SRX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), B), dim3(64), 0, st, a, Hc, Wc, mode);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// =========================================================================================
+// per-axis tap tables of NI_ZoomShift (built on the device, in float64, contraction-free)
+//   TAP_SHIFT: cc = ((i * istep) + shift) + 12, tap indices clamped to [0, len-1]  (mode 'nearest')
+//   TAP_ZOOM : cc = i * zoom; sample = cval 0 if cc outside [0, len-1]; tap indices mirrored
+// =========================================================================================
+enum { TAP_SHIFT = 0, TAP_ZOOM = 1 };
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_build_taps(AxisTap<T> *__restrict__ tab, int n_out, int len, int kind, int istep,
+                                                   double p)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_out)
+        return;
+    AxisTap<T> t;
+    double cc;
+    bool valid = true;
+    if (kind == TAP_SHIFT) {
+        cc = __dadd_rn(__dadd_rn((double)(i * istep), p), (double)SRX_NPAD);
+    } else {
+        cc = __dmul_rn((double)i, p);
+        valid = !(cc < 0.0 || cc > (double)(len - 1));
+    }
+    const double fl = floor(cc);
+    const long start = (long)fl - 1;
+    double w[4];
+    bspline3_weights(cc - fl, w);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long idx = start + k;
+        if (len <= 1) {
+            idx = 0;
+        } else if (kind == TAP_SHIFT) {
+            idx = idx < 0 ? 0 : (idx >= len ? len - 1 : idx);
+        } else {
+            const long s2 = 2L * len - 2;
+            if (idx < 0) {
+                idx = s2 * (long)(-idx / s2) + idx;
+                idx = idx <= 1 - len ? idx + s2 : -idx;
+            } else if (idx >= len) {
+                idx -= s2 * (long)(idx / s2);
+                if (idx >= len)
+                    idx = s2 - idx;
+            }
+        }
+        t.idx[k] = valid ? (int)idx : 0;
+        t.w[k] = valid ? (T)w[k] : (T)0;
+    }
+    tab[i] = t;
+}
+
+template <typename T>
+static int build_taps(AxisTap<T> *tab, int n_out, int len, int kind, int istep, double p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_build_taps<T>, dim3(cdiv(n_out, 64)), dim3(64), 0, st, tab, n_out, len, kind, istep, p);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// out[b,r,c] (+)= sum_a wy[r][a] * sum_b wx[c][b] * coef[b, iy[r][a], ix[c][b]]
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256)
+    k_interp(const T *__restrict__ coef, int Hc, int Wc, const AxisTap<T> *__restrict__ ty,
+             const AxisTap<T> *__restrict__ tx, int Ho, int Wo, T *__restrict__ out)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y * 4 + threadIdx.y;
+    if (r >= Ho || c >= Wo)
+        return;
+    const T *src = coef + (size_t)blockIdx.z * Hc * Wc;
+    const AxisTap<T> a = ty[r], b = tx[c];
+    T acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const T *row = src + (size_t)a.idx[i] * Wc;
+        T racc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            racc += b.w[j] * row[b.idx[j]];
+        acc += a.w[i] * racc;
+    }
+    T *o = out + (size_t)blockIdx.z * Ho * Wo + (size_t)r * Wo + c;
+    *o = ACC ? *o + acc : acc;
+}
+
+template <typename T>
+static int interp(const T *coef, int B, int Hc, int Wc, const AxisTap<T> *ty, const AxisTap<T> *tx, int Ho, int Wo,
+                  T *out, bool accumulate, hipStream_t st)
+{
+    dim3 blk(64, 4), grd(cdiv(Wo, 64), cdiv(Ho, 4), B);
+    if (accumulate)
+        hipLaunchKernelGGL((k_interp<T, true>), grd, blk, 0, st, coef, Hc, Wc, ty, tx, Ho, Wo, out);
+    else
+        hipLaunchKernelGGL((k_interp<T, false>), grd, blk, 0, st, coef, Hc, Wc, ty, tx, Ho, Wo, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// =========================================================================================
+// index maps + pointwise glue
+// =========================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) k_decimate(const T *__restrict__ in, int H, int W, int f, int py, int px, int h,
+                                                  int w, T *__restrict__ out)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (i >= h || j >= w)
+        return;
+    out[(size_t)blockIdx.z * h * w + (size_t)i * w + j] =
+        in[(size_t)blockIdx.z * H * W + (size_t)(py + i * f) * W + px + j * f];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_zero_insert(const T *__restrict__ in, int eh, int ew, int f, int H, int W,
+                                                     T *__restrict__ out)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
+    if (r >= H || c >= W)
+        return;
+    T v = 0;
+    if (r % f == 0 && c % f == 0) {
+        const int i = r / f, j = c / f;
+        if (i < eh && j < ew)
+            v = in[(size_t)blockIdx.z * eh * ew + (size_t)i * ew + j];
+    }
+    out[(size_t)blockIdx.z * H * W + (size_t)r * W + c] = v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_mean_frames(const T *__restrict__ in, int R, size_t n, T *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const T *src = in + (size_t)blockIdx.y * R * n;
+    T acc = 0;
+    for (int r = 0; r < R; r++)
+        acc += src[(size_t)r * n + i];
+    out[(size_t)blockIdx.y * n + i] = acc / (T)R;
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_u8_to(const uint8_t *__restrict__ in, size_t n, T *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (T)in[i];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_quantize_u8(const T *__restrict__ in, size_t n, uint8_t *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T v = in[i];
+        v = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);  // np.clip
+        out[i] = (uint8_t)v;                              // astype(uint8): truncation
+    }
+}
+
+// out = in (copy) / out += in / out /= d
+template <typename T> __global__ void __launch_bounds__(256) k_add(T *__restrict__ out, const T *__restrict__ in, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] += in[i];
+}
+template <typename T> __global__ void __launch_bounds__(256) k_div(T *__restrict__ out, T d, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = out[i] / d;
+}
+
+static inline int grid1d(size_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+// err = lr[:mh,:mw] - sim[:mh,:mw]; errors[b] += sum(err^2) * scale     (run_sr.py:199-202)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_residual(const T *__restrict__ lr, size_t lr_item_stride, int w, const T *__restrict__ sim, size_t sim_item_stride,
+               int sw, int mh, int mw, T *__restrict__ err, double *__restrict__ errors, int errors_stride, double scale)
+{
+    __shared__ double part[4];
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    double sq = 0.0;
+    if (i < mh && j < mw) {
+        const T e = lr[(size_t)b * lr_item_stride + (size_t)i * w + j] - sim[(size_t)b * sim_item_stride + (size_t)i * sw + j];
+        err[(size_t)b * mh * mw + (size_t)i * mw + j] = e;
+        sq = (double)e * (double)e;
+    }
+    sq = wave_sum(sq);
+    if (threadIdx.x == 0)
+        part[threadIdx.y] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && errors)
+        atomicAdd(&errors[(size_t)b * errors_stride], (part[0] + part[1] + part[2] + part[3]) * scale);
+}
+
+// hr = clip(hr + step * corr / n, 0, 255)   (run_sr.py:204-205)
+template <typename T>
+__global__ void __launch_bounds__(256) k_update(T *__restrict__ hr, const T *__restrict__ corr, T step, T n, size_t cnt)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) {
+        T v = hr[i] + step * corr[i] / n;
+        hr[i] = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
+    }
+}
+
+}  // namespace srx

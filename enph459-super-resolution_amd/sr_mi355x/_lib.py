@@ -1,0 +1,94 @@
+"""ctypes binding of libsrx.so (include/srx.h).  No torch types cross this boundary:
+device pointers go through as integers, small parameter arrays as host float64 buffers.
+
+The product path has no CPU fallback: if libsrx.so is missing, load() raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsrx.so")
+_lib = None
+
+OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
+FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED = 0, 1, 2
+
+_c = ctypes
+_P, _I, _D, _Z, _U = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
+_HD = _c.POINTER(_c.c_double)  # host float64 array
+
+# name -> (restype, argtypes) for every symbol include/srx.h declares; {T} expands to f32 and f64
+_TYPED = {
+    "srx_blur_{T}": (_I, [_P, _I, _I, _I, _HD, _I, _I, _P, _P]),
+    "srx_shift_cubic_{T}": (_I, [_P, _I, _I, _I, _D, _D, _P, _P, _Z, _P]),
+    "srx_zoom_cubic_{T}": (_I, [_P, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "srx_forward_{T}": (_I, [_P, _I, _I, _I, _HD, _I, _I, _D, _D, _I, _P, _P, _Z, _P]),
+    "srx_backproject_{T}": (_I, [_P, _I, _I, _I, _HD, _I, _I, _D, _D, _I, _I, _I, _P, _P, _Z, _P]),
+    "srx_saa_{T}": (_I, [_P, _I, _I, _I, _I, _HD, _I, _P, _P, _Z, _P, _U]),
+    "srx_ibp_{T}": (_I, [_P, _I, _I, _I, _I, _HD, _HD, _I, _I, _P, _I, _I, _I, _I, _D, _P, _P, _P, _Z, _P, _U]),
+    "srx_decimate_{T}": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "srx_zero_insert_{T}": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "srx_mean_frames_{T}": (_I, [_P, _I, _I, _Z, _P, _P]),
+    "srx_u8_to_{T}": (_I, [_P, _Z, _P, _P]),
+    "srx_quantize_u8_{T}": (_I, [_P, _Z, _P, _P]),
+}
+_PLAIN = {
+    "srx_version": (_I, []),
+    "srx_strerror": (_c.c_char_p, [_I]),
+    "srx_last_path": (_c.c_char_p, []),
+    "srx_shift_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "srx_zoom_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "srx_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "srx_backproject_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "srx_saa_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "srx_ibp_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _U]),
+}
+
+
+def symbols():
+    """Every symbol name include/srx.h declares."""
+    names = list(_PLAIN)
+    for pat in _TYPED:
+        names += [pat.format(T="f32"), pat.format(T="f64")]
+    return names
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 ... -> sr_mi355x/libsrx.so (cross-compiles without a GPU)."""
+    pkg_root = os.path.dirname(_HERE)
+    if force and os.path.exists(SO_PATH):
+        os.remove(SO_PATH)
+    subprocess.check_call(["make", "-s", "-C", pkg_root])
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
+                           "(sr_mi355x has no CPU fallback)")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in _PLAIN.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for pat, (res, args) in _TYPED.items():
+        for t in ("f32", "f64"):
+            fn = getattr(lib, pat.format(T=t))
+            fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class SrxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = load().srx_strerror(status).decode()
+        super().__init__(f"{where}: {msg} (status {status})")
+
+
+def check(status, where):
+    if status != OK:
+        raise SrxError(status, where)

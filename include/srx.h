@@ -1,0 +1,151 @@
+/*
+ * srx.h -- C ABI of libsrx.so, the MI355X (gfx950) multi-frame super-resolution core.
+ *
+ * Drop-in boundary.  The reference (benedikthoward/ENPH459-Super-Resolution) has no FFI:
+ * its boundary is the set of module-level Python functions each run_sr.py driver calls
+ * (mono_cal_target/run_sr.py:157-209; identical copies in rgb_cal_target :171-223,
+ * mono_barcodes :188-242, rgb_barcodes :201-255).  Every entry point below replaces one
+ * of those functions (or one of the two SciPy calls the drivers make directly) and says
+ * which.  The Python shim `sr_mi355x` (enph459-super-resolution_amd/sr_mi355x/api.py)
+ * binds these with ctypes and re-exposes the reference's names and signatures.
+ *
+ * Conventions
+ *   - Plain C ABI: pointers + sizes, no C++/torch types.  Suffix _f32 / _f64 = element
+ *     type T of every image buffer (float / double).  The reference computes in float64;
+ *     _f64 reproduces it to ~1e-10 DN, _f32 (HBM-bound fast path) to ~2e-4 DN.
+ *   - Image buffers are DEVICE pointers (HBM), C-contiguous, row-major [row(y), col(x)],
+ *     single channel, with a leading batch count B (B independent work items: patches,
+ *     sessions x reps).  B = 1 reproduces the reference's single-image call.
+ *   - Small parameter arrays (PSF kernel, shift table) are HOST pointers, float64:
+ *     `kernel` [kh, kw] row-major, `shifts_yx` [N, 2] = (dy, dx) in LR pixels, positive =
+ *     content moves toward +index -- exactly the reference's `shift_yx`/`shifts_yx`.
+ *     They are shared by all B items of a call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued on it; nothing synchronises the device.  No allocation happens inside a
+ *     call: scratch comes from the caller's workspace (`*_workspace_bytes`, 256-B aligned
+ *     device memory).  Inputs are never written; outputs never alias inputs unless stated.
+ *   - Return value: SRX_OK (0) or a negative srx_status; srx_strerror() names it.  Like the
+ *     reference's core, shape mismatches that the reference handles by crop/pad
+ *     (run_sr.py:172-175, :199-201) are handled the same way, not reported.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *srx_stream_t;
+
+typedef enum {
+    SRX_OK = 0,
+    SRX_E_INVALID = -1,     /* null pointer, non-positive size, bad factor */
+    SRX_E_UNSUPPORTED = -2, /* kernel larger than SRX_MAX_KERNEL_TAPS, N > SRX_MAX_FRAMES ... */
+    SRX_E_WORKSPACE = -3,   /* workspace pointer null or smaller than *_workspace_bytes() */
+    SRX_E_HIP = -4          /* a HIP runtime call or kernel launch failed */
+} srx_status;
+
+#define SRX_MAX_KERNEL_TAPS 225 /* kh * kw <= 15 x 15 */
+#define SRX_MAX_FRAMES 32       /* N per work item */
+
+/* srx_ibp / srx_saa `flags` */
+#define SRX_FLAG_AUTO 0u     /* fused tile kernels when eligible, composed primitives otherwise */
+#define SRX_FLAG_COMPOSED 1u /* force the literal per-frame composition of the primitives */
+#define SRX_FLAG_FUSED 2u    /* require the fused path; SRX_E_UNSUPPORTED if not eligible */
+
+int srx_version(void);
+const char *srx_strerror(int status);
+/* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took ("fused", "composed"). */
+const char *srx_last_path(void);
+
+/* ---- blur(img, kernel): run_sr.py:157-158, fftconvolve(img, kernel, mode='same') ----
+ * zero-padded true convolution, centred crop at (k-1)//2.  img/out [B, H, W]. */
+int srx_blur_f32(const float *img, int B, int H, int W, const double *kernel, int kh, int kw, float *out,
+                 srx_stream_t stream);
+int srx_blur_f64(const double *img, int B, int H, int W, const double *kernel, int kh, int kw, double *out,
+                 srx_stream_t stream);
+
+/* ---- scipy.ndimage.shift(in, (sy, sx), order=3, mode='nearest'): call sites run_sr.py:163-164,
+ * :176-177, :186.  sy/sx in pixels of `in`; out[i] = in[i - s].  in/out [B, H, W]. */
+size_t srx_shift_workspace_bytes(int elem_bytes, int B, int H, int W);
+int srx_shift_cubic_f32(const float *in, int B, int H, int W, double sy, double sx, float *out, void *ws,
+                        size_t ws_bytes, srx_stream_t stream);
+int srx_shift_cubic_f64(const double *in, int B, int H, int W, double sy, double sx, double *out, void *ws,
+                        size_t ws_bytes, srx_stream_t stream);
+
+/* ---- scipy.ndimage.zoom(in, factor, order=3): call sites run_sr.py:185, :279 (Native-2x).
+ * in [B, h, w] -> out [B, h*factor, w*factor]. */
+size_t srx_zoom_workspace_bytes(int elem_bytes, int B, int h, int w, int factor);
+int srx_zoom_cubic_f32(const float *in, int B, int h, int w, int factor, float *out, void *ws, size_t ws_bytes,
+                       srx_stream_t stream);
+int srx_zoom_cubic_f64(const double *in, int B, int h, int w, int factor, double *out, void *ws, size_t ws_bytes,
+                       srx_stream_t stream);
+
+/* ---- forward_model(hr, kernel, shift_yx, factor): run_sr.py:161-165.
+ * hr [B, H, W] -> out [B, ceil(H/f), ceil(W/f)]. */
+size_t srx_forward_workspace_bytes(int elem_bytes, int B, int H, int W);
+int srx_forward_f32(const float *hr, int B, int H, int W, const double *kernel, int kh, int kw, double sy, double sx,
+                    int factor, float *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+int srx_forward_f64(const double *hr, int B, int H, int W, const double *kernel, int kh, int kw, double sy, double sx,
+                    int factor, double *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+
+/* ---- back_project(error_lr, kernel, shift_yx, factor, hr_shape): run_sr.py:168-178.
+ * err [B, eh, ew] -> out [B, H, W] (zero-insert at [::f, ::f], pad/crop to (H, W)). */
+size_t srx_backproject_workspace_bytes(int elem_bytes, int B, int H, int W);
+int srx_backproject_f32(const float *err, int B, int eh, int ew, const double *kernel, int kh, int kw, double sy,
+                        double sx, int factor, int H, int W, float *out, void *ws, size_t ws_bytes,
+                        srx_stream_t stream);
+int srx_backproject_f64(const double *err, int B, int eh, int ew, const double *kernel, int kh, int kw, double sy,
+                        double sx, int factor, int H, int W, double *out, void *ws, size_t ws_bytes,
+                        srx_stream_t stream);
+
+/* ---- shift_and_add(lr_list, shifts_yx, factor, order=3): run_sr.py:181-187.
+ * lr [B, N, h, w] -> out [B, h*f, w*f]. */
+size_t srx_saa_workspace_bytes(int elem_bytes, int B, int N, int h, int w, int factor);
+int srx_saa_f32(const float *lr, int B, int N, int h, int w, const double *shifts_yx, int factor, float *out,
+                void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);
+int srx_saa_f64(const double *lr, int B, int N, int h, int w, const double *shifts_yx, int factor, double *out,
+                void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);
+
+/* ---- ibp(lr_list, shifts_yx, kernel, hr_init, factor, n_iter, step): run_sr.py:190-209.
+ * lr [B, N, h, w], hr_init/hr_out [B, H, W] (hr_out may alias hr_init), errors_out device
+ * float64 [B, n_iter] = the reference's `errors` list per item (mean over frames of the mean
+ * squared LR residual BEFORE that iteration's update); may be NULL to skip it. */
+size_t srx_ibp_workspace_bytes(int elem_bytes, int B, int N, int h, int w, int H, int W, int factor, unsigned flags);
+int srx_ibp_f32(const float *lr, int B, int N, int h, int w, const double *shifts_yx, const double *kernel, int kh,
+                int kw, const float *hr_init, int H, int W, int factor, int n_iter, double step, float *hr_out,
+                double *errors_out, void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);
+int srx_ibp_f64(const double *lr, int B, int N, int h, int w, const double *shifts_yx, const double *kernel, int kh,
+                int kw, const double *hr_init, int H, int W, int factor, int n_iter, double step, double *hr_out,
+                double *errors_out, void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);
+
+/* ---- index maps and pointwise glue of the drivers (bit-exact) ----
+ * decimate:    out[i, j] = in[py + i*f, px + j*f]     `shifted[::f, ::f]` run_sr.py:165;
+ *              with f=2, py=px=0 it is extract_red (rgb_cal_target/run_sr.py:73-75).
+ *              in [B, H, W] -> out [B, ceil((H-py)/f), ceil((W-px)/f)].
+ * zero_insert: out = 0; out[i*f, j*f] = in[i, j] for i*f < H, j*f < W   run_sr.py:170-175.
+ *              in [B, eh, ew] -> out [B, H, W].
+ * mean_frames: out = sum_r in[r] / R   (np.mean(axis=0)) run_sr.py:274, rgb_cal_target :107-108.
+ *              in [B, R, n] -> out [B, n].
+ * u8_to:       uint8 -> T            (load_gray: run_sr.py:73-75)
+ * quantize_u8: np.clip(x, 0, 255).astype(np.uint8) -- clamp then TRUNCATE   run_sr.py:303.
+ */
+int srx_decimate_f32(const float *in, int B, int H, int W, int f, int py, int px, float *out, srx_stream_t stream);
+int srx_decimate_f64(const double *in, int B, int H, int W, int f, int py, int px, double *out, srx_stream_t stream);
+int srx_zero_insert_f32(const float *in, int B, int eh, int ew, int f, int H, int W, float *out, srx_stream_t stream);
+int srx_zero_insert_f64(const double *in, int B, int eh, int ew, int f, int H, int W, double *out,
+                        srx_stream_t stream);
+int srx_mean_frames_f32(const float *in, int B, int R, size_t n, float *out, srx_stream_t stream);
+int srx_mean_frames_f64(const double *in, int B, int R, size_t n, double *out, srx_stream_t stream);
+int srx_u8_to_f32(const uint8_t *in, size_t n, float *out, srx_stream_t stream);
+int srx_u8_to_f64(const uint8_t *in, size_t n, double *out, srx_stream_t stream);
+int srx_quantize_u8_f32(const float *in, size_t n, uint8_t *out, srx_stream_t stream);
+int srx_quantize_u8_f64(const double *in, size_t n, uint8_t *out, srx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

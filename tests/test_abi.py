@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: libsrx.so loads without a GPU and exports every
+symbol include/srx.h declares; the ctypes table and the header agree."""
+import os
+import re
+
+from sr_mi355x import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "srx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(srx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_loads():
+    _lib.build()
+    lib = _lib.load()
+    assert lib.srx_version() >= 100
+    assert lib.srx_strerror(0) == b"ok"
+    assert lib.srx_strerror(-3).startswith(b"workspace")
+
+
+def test_every_declared_symbol_is_exported():
+    _lib.build()
+    lib = _lib.load()
+    hdr = header_symbols()
+    assert len(hdr) >= 30
+    for name in hdr:
+        assert hasattr(lib, name), f"{name} declared in include/srx.h but not exported by libsrx.so"
+    assert sorted(_lib.symbols()) == hdr, "ctypes table and header disagree"
+
+
+def test_workspace_queries_need_no_gpu():
+    lib = _lib.load()
+    a = lib.srx_ibp_workspace_bytes(4, 1, 4, 32, 32, 64, 64, 2, _lib.FLAG_COMPOSED)
+    b = lib.srx_ibp_workspace_bytes(8, 1, 4, 32, 32, 64, 64, 2, _lib.FLAG_COMPOSED)
+    assert 0 < a < b
+    assert lib.srx_shift_workspace_bytes(4, 2, 64, 64) > 2 * 88 * 88 * 4
+    assert lib.srx_saa_workspace_bytes(4, 1, 4, 32, 32, 2) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Invalid arguments are rejected before any HIP call."""
+    lib = _lib.load()
+    assert lib.srx_blur_f32(None, 1, 8, 8, None, 7, 7, None, None) == _lib.E_INVALID
+    assert lib.srx_u8_to_f32(None, 0, None, None) == _lib.E_INVALID
+    assert lib.srx_ibp_f64(None, 1, 4, 8, 8, None, None, 7, 7, None, 16, 16, 2, 1, 0.5, None, None, None, 0, None,
+                           0) == _lib.E_INVALID

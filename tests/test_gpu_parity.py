@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (libsrx.so through the C ABI, via the sr_mi355x shim) against
+(1) golden vectors made by the reference's own functions (tests/golden, tools/make_golden.py)
+and (2) the CPU oracle on seeded inputs.  Tolerances (DN on 0..255 data):
+    f64 : 1e-9 primitives, 1e-8 after 80 IBP iterations           (the reference's precision)
+    f32 : 2e-3 primitives, 1e-2 after 80 IBP iterations, PSNR(build, ref) > 90 dB and
+          |PSNR(build, truth) - PSNR(ref, truth)| < 0.01 dB         (the north-star bar)
+    index maps (decimate / zero-insert / Bayer red / quantiser): bit-exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import sr_mi355x as S  # noqa: E402
+from sr_mi355x import synth  # noqa: E402
+
+PRIM_TOL = {"f64": 1e-9, "f32": 2e-3}
+IBP_TOL = {"f64": 1e-8, "f32": 1e-2}
+ERR_RTOL = {"f64": 1e-10, "f32": 2e-5}
+
+
+@pytest.fixture(params=["f64", "f32"])
+def prec(request):
+    S.set_precision(request.param)
+    yield request.param
+    S.set_precision("f32")
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = float(np.abs(a - b).max())
+    assert d <= tol, f"max |delta| = {d:.3e} > {tol:.1e}"
+
+
+def test_native_library_is_loaded():
+    from sr_mi355x import _lib
+    assert _lib.load().srx_version() >= 100
+    maps = open("/proc/self/maps").read()
+    assert "libsrx.so" in maps
+
+
+def test_blur(prec, g_c1, g_rag):
+    t = PRIM_TOL[prec]
+    close(S.blur(g_c1["truth"], g_c1["psf_g"]), g_c1["blur_g"], t)
+    close(S.blur(g_c1["truth"], g_c1["psf_m"]), g_c1["blur_m"], t)
+    close(S.blur(g_rag["truth"], g_rag["k53"]), g_rag["blur53"], t)
+
+
+def test_shift(prec, g_c1, g_rag):
+    t = PRIM_TOL[prec]
+    close(S.ndi_shift(g_c1["truth"], g_c1["shift_frac_arg"]), g_c1["shift_frac"], t)
+    close(S.ndi_shift(g_c1["truth"], g_c1["shift_int_arg"]), g_c1["shift_int"], t)
+    close(S.ndi_shift(g_rag["truth"], g_rag["shift_big_arg"]), g_rag["shift_big"], t)
+
+
+def test_zoom(prec, g_c1, g_c2s, g_rag):
+    t = PRIM_TOL[prec]
+    close(S.ndi_zoom(g_c1["lr_nom"][0], 2), g_c1["zoom2"], t)
+    close(S.ndi_zoom(g_c2s["lr16"][3], 4), g_c2s["zoom4"], t)
+    close(S.ndi_zoom(g_rag["truth"][:21, :17], 3), g_rag["zoom3"], t)
+
+
+def test_forward_back(prec, g_c1, g_c2s, g_rag):
+    t = PRIM_TOL[prec]
+    for k, s in enumerate(g_c1["shifts_meas"]):
+        close(S.forward_model(g_c1["truth"], g_c1["psf_m"], s, 2), g_c1["fwd_meas"][k], t)
+        e = g_c1["lr_meas"][k].astype(np.float64) - g_c1["fwd_meas"][k]
+        close(S.back_project(e, g_c1["psf_m"], s, 2, g_c1["truth"].shape), g_c1["bp_meas"][k], t)
+    for k, s in enumerate(g_c1["shifts_nom"]):
+        close(S.forward_model(g_c1["truth"], g_c1["psf_g"], s, 2), g_c1["fwd_nom"][k], t)
+    for k in (0, 5, 15):
+        close(S.forward_model(g_c2s["truth"], g_c2s["psf_g"], g_c2s["shifts16"][k], 4), g_c2s["fwd16"][k], t)
+    for k, s in enumerate(g_rag["shifts"]):
+        close(S.forward_model(g_rag["truth"], g_rag["psf_m"], s, 2), g_rag["fwd"][k], t)
+    e = g_rag["lr"][0].astype(np.float64) - g_rag["fwd"][0][:32, :33]
+    close(S.back_project(e, g_rag["psf_m"], g_rag["shifts"][0], 2, g_rag["truth"].shape), g_rag["bp0"], t)
+
+
+def test_shift_and_add(prec, g_c1, g_c2s):
+    t = PRIM_TOL[prec]
+    close(S.shift_and_add(list(g_c1["lr_nom"]), g_c1["shifts_nom"], 2), g_c1["saa_nom"], t)
+    lr_avg = g_c1["lr_reps"].astype(np.float64).mean(axis=0)
+    close(S.shift_and_add(list(lr_avg), g_c1["shifts_meas"], 2), g_c1["saa_meas"], t)
+    close(S.shift_and_add(list(g_c2s["lr16"]), g_c2s["shifts16"], 4), g_c2s["saa16"], t)
+    close(S.shift_and_add(list(g_c2s["lr4"]), g_c2s["shifts4"], 4), g_c2s["saa4"], t)
+
+
+@pytest.mark.parametrize("flags", ["composed", "auto"])
+@pytest.mark.parametrize("n", [1, 2, 10, 80])
+def test_ibp_c1_nominal(prec, g_c1, n, flags):
+    fl = S.FLAG_COMPOSED if flags == "composed" else S.FLAG_AUTO
+    lr = torch.from_numpy(g_c1["lr_nom"].astype(np.float64))[None]
+    hr, errs = S.ibp_batched(lr, g_c1["shifts_nom"], g_c1["psf_g"], g_c1["saa_nom"][None], 2, n, 0.5, flags=fl)
+    close(hr[0].cpu().numpy(), g_c1[f"ibp_nom_{n}"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs[0].cpu().numpy(), g_c1["ibp_nom_errors"][:n], rtol=ERR_RTOL[prec])
+
+
+@pytest.mark.parametrize("flags", ["composed", "auto"])
+@pytest.mark.parametrize("n", [1, 10, 50])
+def test_ibp_c1_measured(prec, g_c1, n, flags):
+    fl = S.FLAG_COMPOSED if flags == "composed" else S.FLAG_AUTO
+    lr_avg = g_c1["lr_reps"].astype(np.float64).mean(axis=0)
+    hr, errs = S.ibp_batched(lr_avg[None], g_c1["shifts_meas"], g_c1["psf_m"], g_c1["saa_meas"][None], 2, n, 0.5,
+                             flags=fl)
+    close(hr[0].cpu().numpy(), g_c1[f"ibp_meas_{n}"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs[0].cpu().numpy(), g_c1["ibp_meas_errors"][:n], rtol=ERR_RTOL[prec])
+
+
+@pytest.mark.parametrize("n", [1, 10, 80])
+def test_ibp_c2_small(prec, g_c2s, n):
+    hr, errs = S.ibp(list(g_c2s["lr16"]), g_c2s["shifts16"], g_c2s["psf_g"], g_c2s["saa16"], 4, n, 0.5, verbose=False)
+    close(hr, g_c2s[f"ibp16_{n}"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs, g_c2s["ibp16_errors"][:n], rtol=ERR_RTOL[prec])
+    hr, errs = S.ibp(list(g_c2s["lr4"]), g_c2s["shifts4"], g_c2s["psf_m"], g_c2s["saa4"], 4, n, 0.5, verbose=False)
+    close(hr, g_c2s[f"ibp4_{n}"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs, g_c2s["ibp4_errors"][:n], rtol=ERR_RTOL[prec])
+
+
+def test_ibp_c2_full_psnr(prec, g_c2f):
+    """Config C2 patch (f=4, N=16, 64x64 LR -> 256x256, 80 iterations): the north-star PSNR bar."""
+    saa = S.shift_and_add(list(g_c2f["lr16"]), g_c2f["shifts16"], 4)
+    close(saa, g_c2f["saa16"], PRIM_TOL[prec])
+    hr, errs = S.ibp(list(g_c2f["lr16"]), g_c2f["shifts16"], g_c2f["psf_g"], saa, 4, 80, 0.5, verbose=False)
+    ref, truth = g_c2f["ibp16_80"], g_c2f["truth"].astype(np.float64)
+    close(hr, ref, IBP_TOL[prec])
+    assert synth.psnr(hr, ref) > 90.0
+    assert abs(synth.psnr(hr, truth) - synth.psnr(ref, truth)) < 0.01
+    np.testing.assert_allclose(errs, g_c2f["ibp16_errors"], rtol=ERR_RTOL[prec])
+    # uint8 outputs (truncating quantiser): <= 1 LSB, >= 99.9 % identical
+    q, qr = S.quantize_u8(hr).astype(np.int16), np.clip(ref, 0, 255).astype(np.uint8).astype(np.int16)
+    assert np.abs(q - qr).max() <= 1 and (q == qr).mean() >= 0.999
+
+
+def test_ibp_ragged(prec, g_rag):
+    hr, errs = S.ibp(list(g_rag["lr"]), g_rag["shifts"], g_rag["psf_m"], g_rag["hr_init"], 2, 10, 0.5, verbose=False)
+    close(hr, g_rag["ibp_10"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs, g_rag["ibp_errors"], rtol=ERR_RTOL[prec])
+
+
+@pytest.mark.parametrize("name", ["mono_tl", "mono_br", "mono_mid", "rgb_tr", "rgb_mid"])
+def test_real_crops(prec, g_real, name):
+    fam = name.split("_")[0]
+    lr = g_real[f"{name}_lr"].astype(np.float64)
+    if fam == "rgb":
+        raw = g_real[f"{name}_raw"]  # uint8 [4 corners, R reps, 96, 96] Bayer crops
+        S.set_precision("f64")       # loader arithmetic is checked bit-exactly in float64
+        lr2 = np.stack([S.mean_frames(np.stack([S.extract_red(r.astype(np.float64)) for r in reps])) for reps in raw])
+        S.set_precision(prec)
+        assert np.array_equal(lr2, lr)
+    shifts = g_real[f"{fam}_shifts"]
+    psf = g_real["psf_g"] if fam == "mono" else g_real["psf_m"]
+    close(S.ndi_zoom(S.mean_frames(lr), 2), g_real[f"{name}_native"], PRIM_TOL[prec])
+    saa = S.shift_and_add(list(lr), shifts, 2)
+    close(saa, g_real[f"{name}_saa"], PRIM_TOL[prec])
+    hr, errs = S.ibp(list(lr), shifts, psf, saa, 2, 10, 0.5, verbose=False)
+    close(hr, g_real[f"{name}_ibp10"], IBP_TOL[prec])
+    np.testing.assert_allclose(errs, g_real[f"{name}_errors"], rtol=ERR_RTOL[prec])
+
+
+def test_index_maps_bit_exact(prec):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 255, (37, 50))
+    if prec == "f32":
+        x = x.astype(np.float32).astype(np.float64)
+    for f in (2, 3, 4):
+        assert np.array_equal(S.decimate(x, f), x[::f, ::f])
+    assert np.array_equal(S.decimate(x, 2, 1, 1), x[1::2, 1::2])
+    assert np.array_equal(S.extract_red(x), x[0::2, 0::2])
+    e = x[:12, :17]
+    for f, shape in ((2, (24, 34)), (2, (27, 31)), (4, (48, 68)), (3, (30, 60))):
+        up = np.zeros((e.shape[0] * f, e.shape[1] * f))
+        up[::f, ::f] = e
+        up = np.pad(up, ((0, max(0, shape[0] - up.shape[0])), (0, max(0, shape[1] - up.shape[1]))))[:shape[0], :shape[1]]
+        assert np.array_equal(S.zero_insert(e, f, shape), up)
+    y = np.concatenate([x.ravel(), [-3.0, 0.0, 0.999, 1.0, 254.9999, 255.0, 300.0, 127.5]])
+    if prec == "f32":
+        y = y.astype(np.float32).astype(np.float64)
+    assert np.array_equal(S.quantize_u8(y), np.clip(y, 0, 255).astype(np.uint8))
+    u8 = rng.integers(0, 256, (5, 9, 11), dtype=np.uint8)
+    assert np.array_equal(S.u8_to_float(u8).cpu().numpy(), u8.astype(np.float64))
+    st = rng.integers(0, 256, (5, 9, 11)).astype(np.float64)
+    if prec == "f64":
+        assert np.array_equal(S.mean_frames(st), st.mean(axis=0))
+
+
+def test_batch_equals_loop(prec, g_c1):
+    """B independent items in one call == B single calls."""
+    rng = np.random.default_rng(11)
+    lr = np.stack([np.clip(g_c1["lr_nom"].astype(np.float64) + rng.normal(0, 3, g_c1["lr_nom"].shape), 0, 255)
+                   for _ in range(3)])
+    saa = S.shift_and_add_batched(lr, g_c1["shifts_nom"], 2)
+    hr, errs = S.ibp_batched(lr, g_c1["shifts_nom"], g_c1["psf_g"], saa, 2, 5, 0.5)
+    for b in range(3):
+        s1 = S.shift_and_add_batched(lr[b:b + 1], g_c1["shifts_nom"], 2)
+        h1, e1 = S.ibp_batched(lr[b:b + 1], g_c1["shifts_nom"], g_c1["psf_g"], s1, 2, 5, 0.5)
+        assert torch.equal(s1[0], saa[b])
+        assert torch.equal(h1[0], hr[b])
+        np.testing.assert_allclose(e1[0].cpu().numpy(), errs[b].cpu().numpy(), rtol=1e-12)
+
+
+def test_errors_are_reported():
+    from sr_mi355x import _lib
+    with pytest.raises(_lib.SrxError):
+        S.blur(np.zeros((8, 8)), np.ones((16, 16)))  # 256 taps > SRX_MAX_KERNEL_TAPS
