@@ -33,11 +33,12 @@ template <typename T> static int copy_items(const T *in, size_t stride, int B, s
 // scipy.ndimage.shift(order 3, 'nearest') sampled at rows i*istep, cols j*istep (istep=1: the full image)
 template <typename T>
 static int shift_sampled(const T *in, int B, int H, int W, double sy, double sx, int istep, int Ho, int Wo, T *out,
-                         bool accumulate, T *pad, AxisTap<T> *ty, AxisTap<T> *tx, bool taps_ready, hipStream_t st)
+                         bool accumulate, T *pad, T *scr, AxisTap<T> *ty, AxisTap<T> *tx, bool taps_ready,
+                         hipStream_t st)
 {
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     SRX_TRY(pad_edge(in, B, H, W, pad, st));
-    SRX_TRY(prefilter2d(pad, B, Hp, Wp, MODE_REFLECT, st));
+    SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
     if (!taps_ready) {
         SRX_TRY(build_taps(ty, Ho, Hp, TAP_SHIFT, istep, -sy, st));  // scipy negates the shift: cc = i + (-s)
         SRX_TRY(build_taps(tx, Wo, Wp, TAP_SHIFT, istep, -sx, st));
@@ -48,7 +49,7 @@ static int shift_sampled(const T *in, int B, int H, int W, double sy, double sx,
 static size_t shift_ws(int eb, int B, int H, int W)
 {
     const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
+    return 2 * align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
 }
 
 template <typename T>
@@ -59,19 +60,20 @@ static int shift_cubic(const T *in, int B, int H, int W, double sy, double sx, T
         return SRX_E_INVALID;
     Arena ar(ws, wsb);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    return shift_sampled(in, B, H, W, sy, sx, 1, H, W, out, false, pad, ty, tx, false, st);
+    return shift_sampled(in, B, H, W, sy, sx, 1, H, W, out, false, pad, scr, ty, tx, false, st);
 }
 
 // scipy.ndimage.zoom(order 3): in [B items, stride in_stride, h, w] -> out [B, Ho, Wo]
 template <typename T>
-static int zoom_into(const T *in, size_t in_stride, int B, int h, int w, int Ho, int Wo, T *out, T *coef,
+static int zoom_into(const T *in, size_t in_stride, int B, int h, int w, int Ho, int Wo, T *out, T *coef, T *cscr,
                      AxisTap<T> *ty, AxisTap<T> *tx, hipStream_t st)
 {
     SRX_TRY(copy_items(in, in_stride, B, (size_t)h * w, coef, st));
-    SRX_TRY(prefilter2d(coef, B, h, w, MODE_MIRROR, st));
+    SRX_TRY(prefilter2d(coef, cscr, B, h, w, MODE_MIRROR, st));
     const double zy = Ho > 1 ? (double)(h - 1) / (double)(Ho - 1) : 1.0;
     const double zx = Wo > 1 ? (double)(w - 1) / (double)(Wo - 1) : 1.0;
     SRX_TRY(build_taps(ty, Ho, h, TAP_ZOOM, 1, zy, st));
@@ -82,7 +84,7 @@ static int zoom_into(const T *in, size_t in_stride, int B, int h, int w, int Ho,
 static size_t zoom_ws(int eb, int B, int h, int w, int f)
 {
     const size_t m = (size_t)(h > w ? h : w) * f;
-    return align_up((size_t)B * h * w * eb) + 2 * align_up(m * sizeof(AxisTap<double>));
+    return 2 * align_up((size_t)B * h * w * eb) + 2 * align_up(m * sizeof(AxisTap<double>));
 }
 
 template <typename T>
@@ -91,11 +93,11 @@ static int zoom_cubic(const T *in, int B, int h, int w, int f, T *out, void *ws,
     if (!in || !out || B <= 0 || h <= 0 || w <= 0 || f <= 0)
         return SRX_E_INVALID;
     Arena ar(ws, wsb);
-    T *coef = ar.take<T>((size_t)B * h * w);
+    T *coef = ar.take<T>((size_t)B * h * w), *cscr = ar.take<T>((size_t)B * h * w);
     AxisTap<T> *ty = ar.take<AxisTap<T>>((size_t)h * f), *tx = ar.take<AxisTap<T>>((size_t)w * f);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    return zoom_into(in, (size_t)h * w, B, h, w, h * f, w * f, out, coef, ty, tx, st);
+    return zoom_into(in, (size_t)h * w, B, h, w, h * f, w * f, out, coef, cscr, ty, tx, st);
 }
 
 // forward_model = decimate(shift(blur(hr)))
@@ -113,12 +115,13 @@ static int forward_model(const T *hr, int B, int H, int W, const double *k, int 
     Arena ar(ws, wsb);
     T *b = ar.take<T>((size_t)B * H * W);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     const int sh = cdiv(H, f), sw = cdiv(W, f);
     AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     SRX_TRY(blur(hr, B, H, W, k, kh, kw, false, b, st));
-    return shift_sampled(b, B, H, W, sy * f, sx * f, f, sh, sw, out, false, pad, ty, tx, false, st);
+    return shift_sampled(b, B, H, W, sy * f, sx * f, f, sh, sw, out, false, pad, scr, ty, tx, false, st);
 }
 
 // back_project = blur_flipped(shift(zero_insert(err), -s f))
@@ -138,12 +141,13 @@ static int back_project(const T *err, int B, int eh, int ew, const double *k, in
     Arena ar(ws, wsb);
     T *up = ar.take<T>((size_t)B * H * W), *s2 = ar.take<T>((size_t)B * H * W);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, err, eh, ew, f, H, W, up);
     SRX_CHECK_LAUNCH();
-    SRX_TRY(shift_sampled(up, B, H, W, -sy * f, -sx * f, 1, H, W, s2, false, pad, ty, tx, false, st));
+    SRX_TRY(shift_sampled(up, B, H, W, -sy * f, -sx * f, 1, H, W, s2, false, pad, scr, ty, tx, false, st));
     return blur(s2, B, H, W, k, kh, kw, true, out, st);
 }
 
@@ -154,8 +158,8 @@ static size_t saa_ws_composed(int eb, int B, int N, int h, int w, int f)
 {
     (void)N;
     const size_t H = (size_t)h * f, W = (size_t)w * f;
-    return align_up((size_t)B * h * w * eb) + align_up((size_t)B * H * W * eb) +
-           align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
+    return 2 * align_up((size_t)B * h * w * eb) + align_up((size_t)B * H * W * eb) +
+           2 * align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
            4 * align_up((H > W ? H : W) * sizeof(AxisTap<double>));
 }
 
@@ -165,8 +169,10 @@ static int saa_composed(const T *lr, int B, int N, int h, int w, const double *s
 {
     const int H = h * f, W = w * f;
     Arena ar(ws, wsb);
-    T *coef = ar.take<T>((size_t)B * h * w), *up = ar.take<T>((size_t)B * H * W);
+    T *coef = ar.take<T>((size_t)B * h * w), *cscr = ar.take<T>((size_t)B * h * w);
+    T *up = ar.take<T>((size_t)B * H * W);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     AxisTap<T> *zy = ar.take<AxisTap<T>>(H), *zx = ar.take<AxisTap<T>>(W);
     AxisTap<T> *ty = ar.take<AxisTap<T>>(H), *tx = ar.take<AxisTap<T>>(W);
     if (!ar.ok)
@@ -175,9 +181,9 @@ static int saa_composed(const T *lr, int B, int N, int h, int w, const double *s
     if (hipMemsetAsync(out, 0, n * sizeof(T), st) != hipSuccess)
         return SRX_E_HIP;
     for (int k = 0; k < N; k++) {
-        SRX_TRY(zoom_into(lr + (size_t)k * h * w, (size_t)N * h * w, B, h, w, H, W, up, coef, zy, zx, st));
-        SRX_TRY(shift_sampled(up, B, H, W, sh[2 * k] * f, sh[2 * k + 1] * f, 1, H, W, out, true, pad, ty, tx, false,
-                              st));
+        SRX_TRY(zoom_into(lr + (size_t)k * h * w, (size_t)N * h * w, B, h, w, H, W, up, coef, cscr, zy, zx, st));
+        SRX_TRY(shift_sampled(up, B, H, W, sh[2 * k] * f, sh[2 * k + 1] * f, 1, H, W, out, true, pad, scr, ty, tx,
+                              false, st));
     }
     hipLaunchKernelGGL(k_div<T>, dim3(grid1d(n)), dim3(256), 0, st, out, (T)N, n);
     SRX_CHECK_LAUNCH();
@@ -194,7 +200,7 @@ static size_t ibp_ws_composed(int eb, int B, int N, int h, int w, int H, int W, 
     (void)w;
     const size_t P = align_up((size_t)B * H * W * eb);
     const size_t sh = cdiv(H, f), sw = cdiv(W, f);
-    return 5 * P + align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
+    return 5 * P + 2 * align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
            2 * align_up((size_t)B * sh * sw * eb) + (size_t)4 * N * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
 }
 
@@ -209,6 +215,7 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
     Arena ar(ws, wsb);
     T *b = ar.take<T>(P), *up = ar.take<T>(P), *s2 = ar.take<T>(P), *bp = ar.take<T>(P), *corr = ar.take<T>(P);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
+    T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     T *sim = ar.take<T>((size_t)B * sh * sw), *err = ar.take<T>((size_t)B * sh * sw);
     AxisTap<T> *taps[4 * SRX_MAX_FRAMES];
     const size_t tl = (size_t)(H > W ? H : W);
@@ -234,7 +241,8 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
         if (hipMemsetAsync(corr, 0, P * sizeof(T), st) != hipSuccess)
             return SRX_E_HIP;
         for (int q = 0; q < N; q++) {
-            SRX_TRY(shift_sampled(b, B, H, W, 0, 0, f, sh, sw, sim, false, pad, taps[4 * q], taps[4 * q + 1], true, st));
+            SRX_TRY(shift_sampled(b, B, H, W, 0, 0, f, sh, sw, sim, false, pad, scr, taps[4 * q], taps[4 * q + 1], true,
+                                  st));
             hipLaunchKernelGGL(k_residual<T>, dim3(cdiv(mw, 64), cdiv(mh, 4), B), dim3(64, 4), 0, st,
                                lr + (size_t)q * h * w, (size_t)N * h * w, w, sim, (size_t)sh * sw, sw, mh, mw, err,
                                errors ? errors + it : nullptr, n_iter, scale);
@@ -242,7 +250,8 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
             hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, err, mh, mw, f, H,
                                W, up);
             SRX_CHECK_LAUNCH();
-            SRX_TRY(shift_sampled(up, B, H, W, 0, 0, 1, H, W, s2, false, pad, taps[4 * q + 2], taps[4 * q + 3], true, st));
+            SRX_TRY(shift_sampled(up, B, H, W, 0, 0, 1, H, W, s2, false, pad, scr, taps[4 * q + 2], taps[4 * q + 3], true,
+                                  st));
             SRX_TRY(blur(s2, B, H, W, k, kh, kw, true, bp, st));
             hipLaunchKernelGGL(k_add<T>, dim3(grid1d(P)), dim3(256), 0, st, corr, bp, P);
             SRX_CHECK_LAUNCH();

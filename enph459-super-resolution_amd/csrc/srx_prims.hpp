@@ -130,105 +130,195 @@ template <typename T> __device__ __forceinline__ T anticausal_init(T cp_last, T 
     return mode == MODE_MIRROR ? (z * cp_prev + cp_last) * z / (z * z - (T)1) : cp_last * (z / (z - (T)1));
 }
 
-// axis 0 (down the columns): one thread per (batch, column); lanes walk adjacent columns -> coalesced.
-template <typename T> __global__ void __launch_bounds__(64) k_prefilter_axis0(T *__restrict__ a, int Hc, int Wc, int mode)
+// Both passes are OUT OF PLACE (src -> dst) and chunked so that long lines are filtered by many
+// threads: a chunk starts its causal recursion WU samples early from a zero state and its
+// anticausal recursion WU samples late; |z|^WU (f32: 20 -> 4e-12, f64: 40 -> 1e-23) is below the
+// format's epsilon, so the result equals the full-line recursion to rounding.  Chunks that touch
+// a line end use SciPy's exact boundary sums.
+template <typename T> struct Warmup;
+template <> struct Warmup<float> { static constexpr int n = 20; };
+template <> struct Warmup<double> { static constexpr int n = 40; };
+#define SRX_PF_CHUNK 256
+
+// axis 0 (down the columns): one thread per (column, chunk, item); lanes walk adjacent columns -> coalesced.
+template <typename T>
+__global__ void __launch_bounds__(64) k_prefilter_axis0(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode)
 {
+    constexpr int WU = Warmup<T>::n;
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= Wc || Hc <= 1)
+    if (c >= Wc)
         return;
-    const T z = pole<T>();
-    T *col = a + (size_t)blockIdx.y * Hc * Wc + c;
     const size_t s = Wc;
-    T prev = causal_init<T>([&](int i) { return (T)6 * col[i * s]; }, Hc, mode);
-    col[0] = prev;
-    for (int i = 1; i < Hc; i++) {
-        prev = (T)6 * col[i * s] + z * prev;
-        col[i * s] = prev;
+    const T *src = src_ + (size_t)blockIdx.z * Hc * Wc + c;
+    T *dst = dst_ + (size_t)blockIdx.z * Hc * Wc + c;
+    const int start = blockIdx.y * SRX_PF_CHUNK, end = min(start + SRX_PF_CHUNK, Hc);
+    if (Hc <= 1) {
+        if (start == 0)
+            dst[0] = src[0];
+        return;
     }
-    T next = anticausal_init<T>(col[(size_t)(Hc - 1) * s], col[(size_t)(Hc - 2) * s], mode);
-    col[(size_t)(Hc - 1) * s] = next;
-    for (int i = Hc - 2; i >= 0; i--) {
-        next = z * (next - col[i * s]);
-        col[i * s] = next;
+    const T z = pole<T>();
+    // ---- causal ----
+    T prev;
+    int i;
+    if (start - WU <= 0) {
+        prev = causal_init<T>([&](int q) { return (T)6 * src[q * s]; }, Hc, mode);
+        if (start == 0)
+            dst[0] = prev;
+        i = 1;
+    } else {
+        prev = 0;
+        i = start - WU;
+    }
+    for (; i < start; i++)
+        prev = (T)6 * src[i * s] + z * prev;
+    T prev2 = prev;  // c+[i-2] once the loop below has advanced
+    for (; i < end; i++) {
+        prev2 = prev;
+        prev = (T)6 * src[i * s] + z * prev;
+        dst[i * s] = prev;
+    }
+    // ---- tail: c+ of the WU samples after the chunk, kept in registers ----
+    const int te = min(end + WU, Hc) - end;
+    T tail[WU];
+    {
+        T p = prev;
+#pragma unroll
+        for (int t = 0; t < WU; t++) {
+            if (t < te)
+                p = (T)6 * src[(size_t)(end + t) * s] + z * p;
+            tail[t] = p;
+        }
+    }
+    // ---- anticausal ----
+    const bool at_end = end + te >= Hc;  // the tail (or the chunk itself) reaches the end of the line
+    T next;
+    if (te == 0) {
+        // chunk ends the line: prev = c+[Hc-1], prev2 = c+[Hc-2]
+        next = anticausal_init<T>(prev, prev2, mode);
+        dst[(size_t)(Hc - 1) * s] = next;
+        i = Hc - 2;
+    } else {
+        next = 0;
+#pragma unroll
+        for (int t = WU - 1; t >= 0; t--) {
+            if (t == te - 1) {
+                const T cp2 = t >= 1 ? tail[t >= 1 ? t - 1 : 0] : prev;
+                next = at_end ? anticausal_init<T>(tail[t], cp2, mode) : tail[t] * (z / (z - (T)1));
+            } else if (t < te - 1) {
+                next = z * (next - tail[t]);
+            }
+        }
+        i = end - 1;
+    }
+    for (; i >= start; i--) {
+        next = z * (next - dst[i * s]);
+        dst[i * s] = next;
     }
 }
 
-// axis 1 (along the rows): one wave per 64 rows; 64x64 tiles staged through LDS so that global
-// traffic stays coalesced while each lane runs the recursion along its own row (stride 65: no
-// bank conflicts).  Two sweeps: causal left->right, anticausal right->left.
-template <typename T> __global__ void __launch_bounds__(64) k_prefilter_axis1(T *__restrict__ a, int Hc, int Wc, int mode)
+// axis 1 (along the rows): one wave per (64 rows, segment of SEG tiles, item).  64x64 tiles are
+// staged through LDS so global traffic stays coalesced while each lane runs the recursion along
+// its own row (row stride 65 words: no bank conflicts).  One warm-up tile before the segment and
+// one tail tile after it play the role of WU above.
+#define SRX_PF_SEG 8
+template <typename T>
+__global__ void __launch_bounds__(64) k_prefilter_axis1(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode)
 {
     __shared__ T tile[64][65];
+    __shared__ T tailt[64][65];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 64;
     const int rows = min(64, Hc - r0);
-    if (Wc <= 1)
+    const T *src = src_ + (size_t)blockIdx.z * Hc * Wc + (size_t)r0 * Wc;
+    T *dst = dst_ + (size_t)blockIdx.z * Hc * Wc + (size_t)r0 * Wc;
+    const int ntile = cdiv(Wc, 64);
+    const int t0 = blockIdx.y * SRX_PF_SEG, t1 = min(t0 + SRX_PF_SEG, ntile);  // own tiles [t0, t1)
+    if (Wc <= 1) {
+        if (t0 == 0 && lane < rows)
+            dst[(size_t)lane * Wc] = src[(size_t)lane * Wc];
         return;
-    T *base = a + (size_t)blockIdx.y * Hc * Wc + (size_t)r0 * Wc;
+    }
     const T z = pole<T>();
-    const int nchunk = cdiv(Wc, 64);
-    T carry = 0;
-    for (int ch = 0; ch < nchunk; ch++) {
-        const int c0 = ch * 64, cw = min(64, Wc - c0);
+    const bool has_tail = t1 < ntile;
+    T carry = 0, carry_prev = 0;
+    // ---- causal: [warm-up tile] own tiles [tail tile] ----
+    for (int t = max(t0 - 1, 0); t < min(t1 + 1, ntile); t++) {
+        const int c0 = t * 64, cw = min(64, Wc - c0);
+        const bool own = t >= t0 && t < t1;
+        T(*buf)[65] = (t == t1) ? tailt : tile;
         for (int rr = 0; rr < rows; rr++)
             if (lane < cw)
-                tile[rr][lane] = base[(size_t)rr * Wc + c0 + lane];
+                buf[rr][lane] = src[(size_t)rr * Wc + c0 + lane];
         __syncthreads();
         if (lane < rows) {
             int j = 0;
-            if (ch == 0) {
-                // boundary sum: needs the first min(n, 64) samples (all in tile 0) -- and for n <= 64 the whole line
-                carry = causal_init<T>([&](int i) { return (T)6 * tile[lane][i]; }, Wc, mode);
-                tile[lane][0] = carry;
+            if (t == 0) {
+                carry = causal_init<T>([&](int q) { return (T)6 * buf[lane][q]; }, Wc, mode);
+                buf[lane][0] = carry;
                 j = 1;
             }
             for (; j < cw; j++) {
-                carry = (T)6 * tile[lane][j] + z * carry;
-                tile[lane][j] = carry;
+                carry_prev = carry;
+                carry = (T)6 * buf[lane][j] + z * carry;
+                buf[lane][j] = carry;
             }
         }
         __syncthreads();
-        for (int rr = 0; rr < rows; rr++)
-            if (lane < cw)
-                base[(size_t)rr * Wc + c0 + lane] = tile[rr][lane];
+        if (own)
+            for (int rr = 0; rr < rows; rr++)
+                if (lane < cw)
+                    dst[(size_t)rr * Wc + c0 + lane] = buf[rr][lane];
         __syncthreads();
     }
-    for (int ch = nchunk - 1; ch >= 0; ch--) {
-        const int c0 = ch * 64, cw = min(64, Wc - c0);
+    // ---- anticausal ----
+    T next = 0;
+    if (has_tail) {
+        const int c0 = t1 * 64, cw = min(64, Wc - c0);
+        if (lane < rows) {
+            // carry / carry_prev are c+ at the last / second-to-last column of the tail tile
+            next = (t1 == ntile - 1) ? anticausal_init<T>(carry, carry_prev, mode) : carry * (z / (z - (T)1));
+            for (int j = cw - 2; j >= 0; j--)
+                next = z * (next - tailt[lane][j]);
+        }
+    }
+    for (int t = t1 - 1; t >= t0; t--) {
+        const int c0 = t * 64, cw = min(64, Wc - c0);
         for (int rr = 0; rr < rows; rr++)
             if (lane < cw)
-                tile[rr][lane] = base[(size_t)rr * Wc + c0 + lane];
+                tile[rr][lane] = dst[(size_t)rr * Wc + c0 + lane];
         __syncthreads();
         if (lane < rows) {
             int j = cw - 1;
-            if (ch == nchunk - 1) {
-                // cp[n-2] lives in this tile unless the last chunk holds a single column
-                const T cp_prev = cw >= 2 ? tile[lane][cw - 2] : base[(size_t)lane * Wc + Wc - 2];
-                carry = anticausal_init<T>(tile[lane][cw - 1], cp_prev, mode);
-                tile[lane][cw - 1] = carry;
+            if (!has_tail && t == t1 - 1) {
+                next = anticausal_init<T>(carry, carry_prev, mode);
+                tile[lane][cw - 1] = next;
                 j = cw - 2;
             }
             for (; j >= 0; j--) {
-                carry = z * (carry - tile[lane][j]);
-                tile[lane][j] = carry;
+                next = z * (next - tile[lane][j]);
+                tile[lane][j] = next;
             }
         }
         __syncthreads();
         for (int rr = 0; rr < rows; rr++)
             if (lane < cw)
-                base[(size_t)rr * Wc + c0 + lane] = tile[rr][lane];
+                dst[(size_t)rr * Wc + c0 + lane] = tile[rr][lane];
         __syncthreads();
     }
 }
 
-// spline_filter(order 3): axis 0 first, then axis 1 (scipy/ndimage/_interpolation.py: spline_filter)
-template <typename T> static int prefilter2d(T *a, int B, int Hc, int Wc, int mode, hipStream_t st)
+// spline_filter(order 3): axis 0 first, then axis 1 (scipy/ndimage/_interpolation.py: spline_filter).
+// a -> scratch (axis 0) -> a (axis 1): the result lands back in `a`.
+template <typename T> static int prefilter2d(T *a, T *scratch, int B, int Hc, int Wc, int mode, hipStream_t st)
 {
     if (B > 65535)
         return SRX_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), B), dim3(64), 0, st, a, Hc, Wc, mode);
+    hipLaunchKernelGGL(k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), cdiv(Hc, SRX_PF_CHUNK), B), dim3(64), 0, st, a, scratch,
+                       Hc, Wc, mode);
     SRX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), B), dim3(64), 0, st, a, Hc, Wc, mode);
+    hipLaunchKernelGGL(k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), cdiv(cdiv(Wc, 64), SRX_PF_SEG), B), dim3(64), 0, st,
+                       scratch, a, Hc, Wc, mode);
     SRX_CHECK_LAUNCH();
     return SRX_OK;
 }
@@ -295,14 +385,14 @@ static int build_taps(AxisTap<T> *tab, int n_out, int len, int kind, int istep, 
 // out[b,r,c] (+)= sum_a wy[r][a] * sum_b wx[c][b] * coef[b, iy[r][a], ix[c][b]]
 template <typename T, bool ACC>
 __global__ void __launch_bounds__(256)
-    k_interp(const T *__restrict__ coef, int Hc, int Wc, const AxisTap<T> *__restrict__ ty,
+    k_interp(const T *__restrict__ coef, size_t coef_item_stride, int Wc, const AxisTap<T> *__restrict__ ty,
              const AxisTap<T> *__restrict__ tx, int Ho, int Wo, T *__restrict__ out)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int r = blockIdx.y * 4 + threadIdx.y;
     if (r >= Ho || c >= Wo)
         return;
-    const T *src = coef + (size_t)blockIdx.z * Hc * Wc;
+    const T *src = coef + (size_t)blockIdx.z * coef_item_stride;
     const AxisTap<T> a = ty[r], b = tx[c];
     T acc = 0;
 #pragma unroll
@@ -318,17 +408,26 @@ __global__ void __launch_bounds__(256)
     *o = ACC ? *o + acc : acc;
 }
 
+// coef items may be strided (one frame of every [N, h, w] stack); out is dense [B, Ho, Wo]
+template <typename T>
+static int interp_strided(const T *coef, size_t coef_item_stride, int B, int Hc, int Wc, const AxisTap<T> *ty,
+                          const AxisTap<T> *tx, int Ho, int Wo, T *out, hipStream_t st, bool accumulate = false)
+{
+    (void)Hc;
+    dim3 blk(64, 4), grd(cdiv(Wo, 64), cdiv(Ho, 4), B);
+    if (accumulate)
+        hipLaunchKernelGGL((k_interp<T, true>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
+    else
+        hipLaunchKernelGGL((k_interp<T, false>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
 template <typename T>
 static int interp(const T *coef, int B, int Hc, int Wc, const AxisTap<T> *ty, const AxisTap<T> *tx, int Ho, int Wo,
                   T *out, bool accumulate, hipStream_t st)
 {
-    dim3 blk(64, 4), grd(cdiv(Wo, 64), cdiv(Ho, 4), B);
-    if (accumulate)
-        hipLaunchKernelGGL((k_interp<T, true>), grd, blk, 0, st, coef, Hc, Wc, ty, tx, Ho, Wo, out);
-    else
-        hipLaunchKernelGGL((k_interp<T, false>), grd, blk, 0, st, coef, Hc, Wc, ty, tx, Ho, Wo, out);
-    SRX_CHECK_LAUNCH();
-    return SRX_OK;
+    return interp_strided(coef, (size_t)Hc * Wc, B, Hc, Wc, ty, tx, Ho, Wo, out, st, accumulate);
 }
 
 // =========================================================================================

@@ -204,3 +204,49 @@ def test_errors_are_reported():
     from sr_mi355x import _lib
     with pytest.raises(_lib.SrxError):
         S.blur(np.zeros((8, 8)), np.ones((16, 16)))  # 256 taps > SRX_MAX_KERNEL_TAPS
+
+
+def test_large_image_chunked_prefilter(prec):
+    """Lines longer than one prefilter chunk (256 rows / 512 columns): shift and zoom vs the oracle."""
+    from oracle import sr_oracle as O
+    O.set_threads(8)
+    rng = np.random.default_rng(5)
+    x = np.rint(rng.uniform(0, 255, (700, 1100)))
+    t = PRIM_TOL[prec]
+    close(S.ndi_shift(x, (0.9445, -0.8677)), O.ndi_shift(x, (0.9445, -0.8677)), t)
+    close(S.ndi_zoom(x[:300, :577], 2), O.ndi_zoom(x[:300, :577], 2), t)
+    O.set_threads(1)
+
+
+@pytest.mark.parametrize("cfg", ["f2_meas", "f2_nom5", "f4_ph16", "f3_k5"])
+def test_fused_path_vs_oracle(prec, cfg):
+    """Fused tile path on an image spanning several tiles/chunks, against the oracle (literal restatement)."""
+    from oracle import sr_oracle as O
+    O.set_threads(8)
+    try:
+        if cfg == "f2_meas":
+            f, shifts, psf, (h, w) = 2, synth.MEASURED_4, synth.asymmetric_psf(), (150, 277)
+        elif cfg == "f2_nom5":
+            f, shifts, psf, (h, w) = 2, synth.NOMINAL_5, synth.gaussian_psf(), (131, 200)
+        elif cfg == "f4_ph16":
+            f, shifts, psf, (h, w) = 4, synth.phase_shifts(4), synth.gaussian_psf(), (70, 90)
+        else:
+            f, shifts, psf, (h, w) = 3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], synth.asymmetric_psf()[1:6, 1:6], (60, 75)
+            psf = psf / psf.sum()
+        truth = synth.truth_image(h * f, w * f, seed=77)
+        lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=78)
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5)
+    finally:
+        O.set_threads(1)
+    saa = S.shift_and_add(list(lr), shifts, f)
+    assert S.last_path() == "fused"
+    close(saa, saa_o, PRIM_TOL[prec])
+    hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
+    assert S.last_path() == "fused"
+    close(hr, hr_o, IBP_TOL[prec])
+    np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
+    # and the composed (literal) HIP path agrees with the fused one
+    hr_c, errs_c = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_COMPOSED)
+    assert S.last_path() == "composed"
+    close(hr_c[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
