@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- HR megapixels/s of the SR hot path (SAA + IBP) on N MI355X of one node.
+
+A "step" = one complete reconstruction (shift_and_add + ibp(n_iter)) of one batch of synthetic
+patches, with every input already resident in HBM.  The workload is BASELINE.json configs[1] as
+SURVEY.md section 8d grounds it (C2): x4 upscale, 64x64 LR patches -> 256x256 HR, N=16 frames at
+all 4x4 sub-pixel phases (fractional HR shifts), 7x7 Gaussian PSF, 80 IBP iterations, step 0.5,
+B=1024 patches per GPU.  Patches are independent work items: ranks own disjoint patches, no
+collective on the data path ("scaling": "weak"); torch.distributed is used only for the barrier
+and the max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  Besides the contract's keys it carries
+  roofline     : dominant kernel, duration measured live with HIP events on the launch stream
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference's algorithm) timed on this
+                 host's cores on a bounded sample of the same workload -- a reported baseline only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "enph459-super-resolution_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def make_inputs(S, synth, B, f, lr_hw, shifts, psf, n_unique, prec, seed_base):
+    """Synthetic 'DIV2K-shaped' patches: truth images from synth.truth_image, LR frames through the
+    product's own forward model + sensor noise (sigma 1 DN), rounded and clipped to the uint8 range."""
+    h, w = lr_hw
+    H, W = h * f, w * f
+    truths = np.stack([synth.truth_image(H, W, seed=seed_base + i) for i in range(n_unique)])
+    tt = torch.from_numpy(truths).cuda()
+    frames = torch.stack([S.forward_model_batched(tt, psf, s, f, precision=prec) for s in shifts], dim=1)  # [U,N,h,w]
+    reps = (B + n_unique - 1) // n_unique
+    lr = frames.repeat(reps, 1, 1, 1)[:B].contiguous()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(synth.SEED_NOISE + seed_base)
+    lr = torch.clamp(torch.round(lr + torch.randn(lr.shape, generator=gen, device="cuda", dtype=lr.dtype)), 0, 255)
+    return lr.contiguous(), truths
+
+
+def kernel_model_bytes(name, B, N, h, w, f, eb):
+    """Algorithmic (minimum) HBM bytes of ONE launch of a fused-path kernel at these shapes."""
+    H, W = h * f, w * f
+    hw, pad, lrn = B * H * W * eb, B * (H + 24) * (W + 24) * eb, B * N * h * w * eb
+    return {
+        "k_blur_pad": hw + pad,                 # read hr, write padded blur
+        "k_prefilter_axis0": 2 * pad,           # read + write the padded plane
+        "k_prefilter_axis1": 2 * pad,
+        "k_fwd_residual": pad + 2 * lrn,        # read coefficients + LR frames, write residuals
+        "k_back_gather": lrn + pad,             # read residuals, write padded gather
+        "k_blurT_update": pad + 2 * hw,         # read padded coefficients + hr, write hr
+    }.get(name)
+
+
+def cpu_baseline(synth, f, lr_hw, shifts, psf, n_iter, step):
+    """The oracle (a CPU port of the reference's algorithm, float64) on ONE patch, 1 thread like the
+    reference (scipy.ndimage / pocketfft are single-threaded), full SAA + IBP(n_iter)."""
+    from oracle import sr_oracle as O
+    h, w = lr_hw
+    H, W = h * f, w * f
+    truth = synth.truth_image(H, W, seed=synth.SEED_TRUTH)
+    O.set_threads(1)
+    lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]))
+    t0 = time.perf_counter()
+    saa = O.shift_and_add(list(lr), shifts, f)
+    hr, _ = O.ibp(list(lr), shifts, psf, saa, f, n_iter, step)
+    dt = time.perf_counter() - t0
+    out = {"value": H * W / 1e6 / dt, "unit": "HR-MP/s", "cores": 1, "kind": "port",
+           "sample": f"1 patch of the same workload ({h}x{w} LR -> {H}x{W}, N={len(shifts)}, SAA + {n_iter} IBP "
+                     f"iterations, float64), {dt:.1f} s on 1 thread", "host_cores": os.cpu_count()}
+    # all host cores (OpenMP over rows/columns inside each primitive), for scale
+    nthr = min(os.cpu_count() or 1, 16)
+    O.set_threads(nthr)
+    t0 = time.perf_counter()
+    saa = O.shift_and_add(list(lr), shifts, f)
+    O.ibp(list(lr), shifts, psf, saa, f, max(1, n_iter // 4), step)
+    dt2 = (time.perf_counter() - t0) * (n_iter / max(1, n_iter // 4))
+    O.set_threads(1)
+    out["value_all_threads"] = H * W / 1e6 / dt2
+    out["threads_all"] = nthr
+    return out, hr, lr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
+    ap.add_argument("--iters", type=int, default=80, help="IBP iterations (reference default 80)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import sr_mi355x as S
+    from sr_mi355x import synth, _lib
+
+    prec = args.precision
+    S.set_precision(prec)
+    f, lr_hw, n_iter, step = 4, (64, 64), args.iters, 0.5
+    shifts = synth.phase_shifts(4)
+    N = len(shifts)
+    psf = synth.gaussian_psf()
+    B = args.batch
+    h, w = lr_hw
+    H, W = h * f, w * f
+
+    lr, _ = make_inputs(S, synth, B, f, lr_hw, shifts, psf, n_unique=32, prec=prec, seed_base=1000 * (rank + 1))
+    torch.cuda.synchronize()
+
+    def one_step():
+        saa = S.shift_and_add_batched(lr, shifts, f, precision=prec)
+        hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n_iter, step, precision=prec, out=saa)
+        return hr, errs
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hr, errs = one_step()
+    path = S.last_path()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hr, errs = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    hr_mp = world * B * H * W / 1e6
+    value = hr_mp * args.steps / dt
+    sane = bool(torch.isfinite(hr).all().item()) and float(errs[:, -1].mean().item()) < float(errs[:, 0].mean().item())
+
+    # ---- roofline leg: one extra, untimed step with HIP events around every fused-path launch ----
+    roofline, kernels = None, {}
+    if rank == 0 and not args.no_roofline:
+        lib = _lib.load()
+        lib.srx_profile_enable(1)
+        one_step()
+        torch.cuda.synchronize()
+        eb = 4 if prec == "f32" else 8
+        tot, cnt = ctypes.c_double(), ctypes.c_long()
+        for kid in range(lib.srx_profile_kernel_count()):
+            _lib.check(lib.srx_profile_get(kid, ctypes.byref(tot), ctypes.byref(cnt)), "srx_profile_get")
+            if cnt.value:
+                kernels[lib.srx_profile_kernel_name(kid).decode()] = {"launches": cnt.value, "total_ms": round(tot.value, 3),
+                                                                      "avg_us": round(tot.value / cnt.value * 1e3, 2)}
+        lib.srx_profile_enable(0)
+        ibp_k = {k: v for k, v in kernels.items() if kernel_model_bytes(k, B, N, h, w, f, eb)}
+        if ibp_k:
+            dom = max(ibp_k, key=lambda k: ibp_k[k]["total_ms"])
+            nbytes = kernel_model_bytes(dom, B, N, h, w, f, eb)
+            ach = nbytes / (ibp_k[dom]["avg_us"] * 1e-6) / 1e9
+            t_iter_us = sum(v["total_ms"] for v in ibp_k.values()) * 1e3 / n_iter
+            it_bytes = (2 * eb + eb * N / (f * f)) * B * H * W  # 8 + 4N/f^2 B per HR px per iteration (f32)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": ibp_k[dom]["avg_us"],
+                        "iteration": {"algorithmic_bytes": it_bytes, "kernel_time_us": round(t_iter_us, 1),
+                                      "achieved": round(it_bytes / (t_iter_us * 1e-6) / 1e9, 1),
+                                      "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+            tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC pass (tools/collect_pmc.py), per launch
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                if tj.get("workload") == f"C2:B={B}" and dom in tj.get("kernels", {}):
+                    roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, hr_cpu, lr_cpu = cpu_baseline(synth, f, lr_hw, shifts, psf, n_iter, step)
+        # parity spot check of the same patch on the GPU (the oracle is only the checker here)
+        saa_g = S.shift_and_add_batched(torch.from_numpy(lr_cpu)[None], shifts, f, precision=prec)
+        hr_g, _ = S.ibp_batched(torch.from_numpy(lr_cpu)[None], shifts, psf, saa_g, f, n_iter, step, precision=prec)
+        cpu["psnr_gpu_vs_cpu_db"] = round(synth.psnr(hr_g[0].double().cpu().numpy(), hr_cpu), 2)
+
+    if rank == 0:
+        line = {
+            "metric": "HR megapixels/sec at x4 upscale (SAA + 80-iteration IBP reconstruction)",
+            "value": round(value, 2), "unit": "HR-MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": prec, "data": "synthetic",
+            "config": {"workload": "C2: x4 multi-frame SR of 64x64 LR patches -> 256x256 HR, N=16 frames (all 4x4 "
+                                   "sub-pixel phases), 7x7 Gaussian PSF, shift_and_add + ibp(80 it, step 0.5)",
+                       "patches_per_gpu": B, "global_patches": world * B, "factor": f, "frames": N, "lr_patch": [h, w],
+                       "n_iter": n_iter, "path": path, "parallelism": f"patch-sharded x{world}, no collective"},
+            "hr_mp_iter_per_s": round(value * n_iter, 1), "sane": sane,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,18 @@ using namespace srx;
 
 static thread_local const char *g_last_path = "none";
 
+namespace srx {
+Profiler &profiler()
+{
+    static Profiler p;
+    return p;
+}
+}  // namespace srx
+
+static const char *const g_kernel_names[KID_COUNT] = {
+    "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
+    "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div"};
+
 // ---------------------------------------------------------------------------------------
 // composed building blocks
 // ---------------------------------------------------------------------------------------
@@ -331,6 +343,37 @@ const char *srx_strerror(int s)
 }
 
 const char *srx_last_path(void) { return g_last_path; }
+
+void srx_profile_enable(int on)
+{
+    profiler().clear();
+    profiler().on = on != 0;
+}
+
+int srx_profile_kernel_count(void) { return KID_COUNT; }
+
+const char *srx_profile_kernel_name(int id) { return id >= 0 && id < KID_COUNT ? g_kernel_names[id] : ""; }
+
+int srx_profile_get(int id, double *total_ms, long *launches)
+{
+    if (id < 0 || id >= KID_COUNT || !total_ms || !launches)
+        return SRX_E_INVALID;
+    Profiler &pf = profiler();
+    double tot = 0.0;
+    long cnt = 0;
+    for (size_t i = 0; i < pf.n; i++) {
+        if (pf.rec[i].id != id)
+            continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(pf.rec[i].b) != hipSuccess || hipEventElapsedTime(&ms, pf.rec[i].a, pf.rec[i].b) != hipSuccess)
+            return SRX_E_HIP;
+        tot += ms;
+        cnt++;
+    }
+    *total_ms = tot;
+    *launches = cnt;
+    return SRX_OK;
+}
 
 size_t srx_shift_workspace_bytes(int eb, int B, int H, int W) { return shift_ws(eb, B, H, W); }
 size_t srx_zoom_workspace_bytes(int eb, int B, int h, int w, int f) { return zoom_ws(eb, B, h, w, f); }

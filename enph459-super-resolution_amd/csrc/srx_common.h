@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "srx.h"
 
@@ -47,6 +48,67 @@ struct Arena {
 };
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
+enum KernelId {
+    KID_BLUR_PAD = 0,
+    KID_PREFILTER_AXIS0,
+    KID_PREFILTER_AXIS1,
+    KID_FWD_RESIDUAL,
+    KID_BACK_GATHER,
+    KID_BLURT_UPDATE,
+    KID_ZOOM_INTERP,
+    KID_FIR_PAD,
+    KID_CROP_DIV,
+    KID_COUNT
+};
+
+struct ProfRecord {
+    int id;
+    hipEvent_t a, b;
+};
+
+struct Profiler {
+    bool on = false;
+    ProfRecord *rec = nullptr;
+    size_t n = 0, cap = 0;
+    void begin(int id, hipStream_t st)
+    {
+        if (n == cap) {
+            cap = cap ? cap * 2 : 4096;
+            rec = (ProfRecord *)realloc(rec, cap * sizeof(ProfRecord));
+        }
+        ProfRecord &r = rec[n];
+        r.id = id;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+    }
+    void end(hipStream_t st) { (void)hipEventRecord(rec[n++].b, st); }
+    void clear()
+    {
+        for (size_t i = 0; i < n; i++) {
+            (void)hipEventDestroy(rec[i].a);
+            (void)hipEventDestroy(rec[i].b);
+        }
+        n = 0;
+    }
+};
+
+Profiler &profiler();
+
+// launch a kernel, timing it when profiling is on
+#define SRX_LAUNCH(ID, KERNEL, GRID, BLOCK, SHMEM, ST, ...)                   \
+    do {                                                                      \
+        srx::Profiler &_pf = srx::profiler();                                 \
+        if (_pf.on)                                                           \
+            _pf.begin(ID, ST);                                                \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, ST, __VA_ARGS__);      \
+        if (_pf.on)                                                           \
+            _pf.end(ST);                                                      \
+        if (hipGetLastError() != hipSuccess)                                  \
+            return SRX_E_HIP;                                                 \
+    } while (0)
 
 #define SRX_CHECK_LAUNCH()                       \
     do {                                         \

@@ -366,19 +366,15 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
-        hipLaunchKernelGGL(k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
-        SRX_CHECK_LAUNCH();
+        SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
-        hipLaunchKernelGGL(k_fwd_residual<T>, dim3(cdiv(w, 16), cdiv(h, 16), B), dim3(16, 16),
-                           (size_t)th * tw * sizeof(T), st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omin_x, th, tw, err,
-                           errors ? errors + it : nullptr, n_iter, scale);
-        SRX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_back_gather<T>, dim3(cdiv(Wp, 64), cdiv(Hp, 4), B), dim3(64, 4), 0, st, err, h, w, f, bwd, H,
-                           W, pad);
-        SRX_CHECK_LAUNCH();
+        SRX_LAUNCH(KID_FWD_RESIDUAL, k_fwd_residual<T>, dim3(cdiv(w, 16), cdiv(h, 16), B), dim3(16, 16),
+                   (size_t)th * tw * sizeof(T), st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omin_x, th, tw, err,
+                   errors ? errors + it : nullptr, n_iter, scale);
+        SRX_LAUNCH(KID_BACK_GATHER, k_back_gather<T>, dim3(cdiv(Wp, 64), cdiv(Hp, 4), B), dim3(64, 4), 0, st, err, h, w, f,
+                   bwd, H, W, pad);
         SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
-        hipLaunchKernelGGL(k_blurT_update<T>, bgrid, bblk, 0, st, pad, H, W, kt, (T)step, (T)N, cur, hr);
-        SRX_CHECK_LAUNCH();
+        SRX_LAUNCH(KID_BLURT_UPDATE, k_blurT_update<T>, bgrid, bblk, 0, st, pad, H, W, kt, (T)step, (T)N, cur, hr);
     }
     return SRX_OK;
 }
@@ -419,14 +415,12 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         make_tap<T>(-sh[2 * q] * f, -sh[2 * q + 1] * f, 0, ft);  // shift(+d): out[r] = in[r - d]
         const dim3 grd(cdiv(Wp, 64), cdiv(Hp, 4), B), blk(64, 4);
         if (q == 0)
-            hipLaunchKernelGGL((k_fir_pad<T, false>), grd, blk, 0, st, up, H, W, ft, pad);
+            SRX_LAUNCH(KID_FIR_PAD, (k_fir_pad<T, false>), grd, blk, 0, st, up, H, W, ft, pad);
         else
-            hipLaunchKernelGGL((k_fir_pad<T, true>), grd, blk, 0, st, up, H, W, ft, pad);
-        SRX_CHECK_LAUNCH();
+            SRX_LAUNCH(KID_FIR_PAD, (k_fir_pad<T, true>), grd, blk, 0, st, up, H, W, ft, pad);
     }
     SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
-    hipLaunchKernelGGL(k_crop_div<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, pad, H, W, (T)N, out);
-    SRX_CHECK_LAUNCH();
+    SRX_LAUNCH(KID_CROP_DIV, k_crop_div<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, pad, H, W, (T)N, out);
     return SRX_OK;
 }
 

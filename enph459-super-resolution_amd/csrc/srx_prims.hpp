@@ -314,12 +314,10 @@ template <typename T> static int prefilter2d(T *a, T *scratch, int B, int Hc, in
 {
     if (B > 65535)
         return SRX_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), cdiv(Hc, SRX_PF_CHUNK), B), dim3(64), 0, st, a, scratch,
-                       Hc, Wc, mode);
-    SRX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), cdiv(cdiv(Wc, 64), SRX_PF_SEG), B), dim3(64), 0, st,
-                       scratch, a, Hc, Wc, mode);
-    SRX_CHECK_LAUNCH();
+    SRX_LAUNCH(KID_PREFILTER_AXIS0, k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), cdiv(Hc, SRX_PF_CHUNK), B), dim3(64), 0, st,
+               a, scratch, Hc, Wc, mode);
+    SRX_LAUNCH(KID_PREFILTER_AXIS1, k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), cdiv(cdiv(Wc, 64), SRX_PF_SEG), B),
+               dim3(64), 0, st, scratch, a, Hc, Wc, mode);
     return SRX_OK;
 }
 
@@ -416,10 +414,9 @@ static int interp_strided(const T *coef, size_t coef_item_stride, int B, int Hc,
     (void)Hc;
     dim3 blk(64, 4), grd(cdiv(Wo, 64), cdiv(Ho, 4), B);
     if (accumulate)
-        hipLaunchKernelGGL((k_interp<T, true>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
+        SRX_LAUNCH(KID_ZOOM_INTERP, (k_interp<T, true>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
     else
-        hipLaunchKernelGGL((k_interp<T, false>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
-    SRX_CHECK_LAUNCH();
+        SRX_LAUNCH(KID_ZOOM_INTERP, (k_interp<T, false>), grd, blk, 0, st, coef, coef_item_stride, Wc, ty, tx, Ho, Wo, out);
     return SRX_OK;
 }
 

@@ -37,6 +37,10 @@ _PLAIN = {
     "srx_version": (_I, []),
     "srx_strerror": (_c.c_char_p, [_I]),
     "srx_last_path": (_c.c_char_p, []),
+    "srx_profile_enable": (None, [_I]),
+    "srx_profile_kernel_count": (_I, []),
+    "srx_profile_kernel_name": (_c.c_char_p, [_I]),
+    "srx_profile_get": (_I, [_I, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
     "srx_shift_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "srx_zoom_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "srx_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),

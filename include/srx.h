@@ -61,6 +61,15 @@ const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took ("fused", "composed"). */
 const char *srx_last_path(void);
 
+/* ---- measurement hook (no reference counterpart; used by bench.py's roofline leg) ----
+ * While enabled, every launch of the fused-path kernels is bracketed by HIP events recorded on the
+ * launch stream.  srx_profile_get() waits for them and returns the summed duration and the launch
+ * count of kernel `id` (0 <= id < srx_profile_kernel_count()).  srx_profile_enable() clears the log. */
+void srx_profile_enable(int on);
+int srx_profile_kernel_count(void);
+const char *srx_profile_kernel_name(int id);
+int srx_profile_get(int id, double *total_ms, long *launches);
+
 /* ---- blur(img, kernel): run_sr.py:157-158, fftconvolve(img, kernel, mode='same') ----
  * zero-padded true convolution, centred crop at (k-1)//2.  img/out [B, H, W]. */
 int srx_blur_f32(const float *img, int B, int H, int W, const double *kernel, int kh, int kw, float *out,
