@@ -62,6 +62,8 @@ def kernel_model_bytes(name, B, N, h, w, f, eb):
         "k_fwd_residual": pad + 2 * lrn,        # read coefficients + LR frames, write residuals
         "k_back_gather": lrn + pad,             # read residuals, write padded gather
         "k_blurT_update": pad + 2 * hw,         # read padded coefficients + hr, write hr
+        "k_fwd_tile": pad + 2 * lrn,            # read padded blur + LR frames, write residuals
+        "k_bwd_tile": lrn + 2 * hw,             # read residuals + hr, write hr
     }.get(name)
 
 

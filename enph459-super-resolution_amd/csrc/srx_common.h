@@ -60,6 +60,8 @@ enum KernelId {
     KID_ZOOM_INTERP,
     KID_FIR_PAD,
     KID_CROP_DIV,
+    KID_FWD_TILE,
+    KID_BWD_TILE,
     KID_COUNT
 };
 

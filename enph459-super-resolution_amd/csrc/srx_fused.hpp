@@ -107,7 +107,8 @@ static inline bool saa_eligible(int N, int h, int w, const double *sh, int f)
 #define SRX_BT_H 32
 #define SRX_BT_LDW 72
 
-template <typename T> __device__ __forceinline__ void corr7_strip8(const T *tile, int tx, int ty, const Kernel7<T> &ka, T acc[8])
+template <typename T, int LDW = SRX_BT_LDW>
+__device__ __forceinline__ void corr7_strip8(const T *tile, int tx, int ty, const Kernel7<T> &ka, T acc[8])
 {
 #pragma unroll
     for (int o = 0; o < 8; o++)
@@ -115,7 +116,7 @@ template <typename T> __device__ __forceinline__ void corr7_strip8(const T *tile
 #pragma unroll
     for (int sr = 0; sr < 14; sr++) {
         T v[7];
-        const T *row = tile + (ty * 8 + sr) * SRX_BT_LDW + tx;
+        const T *row = tile + (ty * 8 + sr) * LDW + tx;
 #pragma unroll
         for (int n = 0; n < 7; n++)
             v[n] = row[n];
@@ -322,6 +323,271 @@ __global__ void __launch_bounds__(256) k_crop_div(const T *__restrict__ vpad, in
         vpad[(size_t)blockIdx.z * Hp * Wp + (size_t)(r + SRX_NPAD) * Wp + c + SRX_NPAD] / d;
 }
 
+// =========================================================================================
+// v2: tile kernels with the spline prefilter done INSIDE the tile (LDS), so one iteration is
+//     k_blur_pad -> k_fwd_tile -> k_bwd_tile  (3 launches, no stand-alone prefilter passes).
+// The recursive prefilter has a global dependence along each line, but its impulse response
+// decays as |z|^n, z = sqrt(3)-2: a tile that starts the recursion R samples outside the region
+// it needs (zero state) reproduces the full-line result to |z|^R.  R = 12 for float (1.4e-7 of
+// the local signal, below float epsilon * gain), R = 32 for double (5e-19).  Where the region
+// reaches an end of the padded array the exact SciPy boundary sum is used instead.
+// =========================================================================================
+template <typename T> struct TileCfg;
+template <> struct TileCfg<float> { static constexpr int R = 12, T_HR = 64; };
+template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
+
+// in-place 2-D prefilter of an LDS region [nr x nc], row stride ld (odd: conflict-free row walks)
+template <typename T, int NT>
+__device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, int ld, bool top_edge, bool left_edge, int tid)
+{
+    const T z = pole<T>();
+    const T zfin = z / (z - (T)1);
+    constexpr int K = Warmup<T>::n;
+    for (int c = tid; c < nc; c += NT) {  // axis 0: one thread per column
+        T *col = reg + c;
+        T prev = 0;
+        if (top_edge) {
+            T zi = 1, acc = 0;
+            const int kk = min(K, nr);
+            for (int i = 0; i < kk; i++) {
+                acc += zi * col[i * ld];
+                zi *= z;
+            }
+            prev = (T)6 * acc;  // c+[0] = 6 x[0] + z * sum_i z^i 6 x[i]   ('reflect' end)
+        }
+#pragma unroll 4
+        for (int i = 0; i < nr; i++) {
+            prev = (T)6 * col[i * ld] + z * prev;
+            col[i * ld] = prev;
+        }
+        T next = prev * zfin;
+        col[(nr - 1) * ld] = next;
+#pragma unroll 4
+        for (int i = nr - 2; i >= 0; i--) {
+            next = z * (next - col[i * ld]);
+            col[i * ld] = next;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < nr; r += NT) {  // axis 1: one thread per row
+        T *row = reg + r * ld;
+        T prev = 0;
+        if (left_edge) {
+            T zi = 1, acc = 0;
+            const int kk = min(K, nc);
+            for (int i = 0; i < kk; i++) {
+                acc += zi * row[i];
+                zi *= z;
+            }
+            prev = (T)6 * acc;
+        }
+#pragma unroll 4
+        for (int i = 0; i < nc; i++) {
+            prev = (T)6 * row[i] + z * prev;
+            row[i] = prev;
+        }
+        T next = prev * zfin;
+        row[nc - 1] = next;
+#pragma unroll 4
+        for (int i = nc - 2; i >= 0; i--) {
+            next = z * (next - row[i]);
+            row[i] = next;
+        }
+    }
+    __syncthreads();
+}
+
+// FWD: err[b,k,i,j] = lr[b,k,i,j] - (F_k P bpad)[f i, f j];  errors[b] += sum err^2 * scale.
+// One block per LR tile th x tw (f*th <= T_HR).  grid (ceil(w/tw), ceil(h/th), B), block 256.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_fwd_tile(const T *__restrict__ bpad, int Hp, int Wp, const T *__restrict__ lr, int h, int w, int f,
+               FrameSet<T> fs, int omin_y, int omax_y, int omin_x, int omax_x, int th, int tw, T *__restrict__ err,
+               double *__restrict__ errors, int errors_stride, double scale)
+{
+    constexpr int R = TileCfg<T>::R, FR = TileCfg<T>::T_HR + 12 + 2 * R, LD = FR + 1;
+    __shared__ T reg[FR * LD];
+    __shared__ double part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * th, j0 = blockIdx.x * tw, b = blockIdx.z;
+    const int i1 = min(i0 + th, h), j1 = min(j0 + tw, w);
+    const int pa = max(0, f * i0 + omin_y - R), pb = min(Hp - 1, f * (i1 - 1) + omax_y + 3 + R);
+    const int qa = max(0, f * j0 + omin_x - R), qb = min(Wp - 1, f * (j1 - 1) + omax_x + 3 + R);
+    const int nr = pb - pa + 1, nc = qb - qa + 1;
+    const T *src = bpad + (size_t)b * Hp * Wp + (size_t)pa * Wp + qa;
+    for (int rr = wave; rr < nr; rr += 4)
+        for (int cc = lane; cc < nc; cc += 64)
+            reg[rr * LD + cc] = src[(size_t)rr * Wp + cc];
+    __syncthreads();
+    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid);
+    const int N = fs.n;
+    double sq = 0.0;
+    for (int idx = tid; idx < th * tw; idx += 256) {
+        const int ti = idx / tw, tj = idx - ti * tw;
+        const int i = i0 + ti, j = j0 + tj;
+        if (i >= h || j >= w)
+            continue;
+        for (int k = 0; k < N; k++) {
+            const FrameTap<T> &ft = fs.f[k];
+            const T *p = reg + (f * i + ft.oy - pa) * LD + (f * j + ft.ox - qa);
+            T acc = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                T racc = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    racc += ft.wx[q] * p[a * LD + q];
+                acc += ft.wy[a] * racc;
+            }
+            const size_t o = ((size_t)b * N + k) * h * w + (size_t)i * w + j;
+            const T e = lr[o] - acc;
+            err[o] = e;
+            sq += (double)e * (double)e;
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0)
+        part[wave] = sq;
+    __syncthreads();
+    if (tid == 0 && errors)
+        atomicAdd(&errors[(size_t)b * errors_stride], (part[0] + part[1] + part[2] + part[3]) * scale);
+}
+
+// Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= 2 LR samples
+// the 4-tap window of F_k touches (edge clamping merged in), so that
+//   v[p,q] = sum_k sum_{m,n<2} ty[k][p].w[m] tx[k][q].w[n] err_k[ty.j0+m][tx.j0+n]
+template <typename T> struct LTap {
+    int j0;
+    T w[2];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+    k_build_ltaps(LTap<T> *__restrict__ tab, int len_pad, int n_img, int f, FrameSet<T> fs, int axis)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+    if (p >= len_pad)
+        return;
+    const FrameTap<T> &ft = fs.f[k];
+    const int o = axis == 0 ? ft.oy : ft.ox;
+    LTap<T> t;
+    t.j0 = -1;
+    t.w[0] = t.w[1] = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int y = min(max(p + o + a - SRX_NPAD, 0), n_img - 1);
+        if (y % f == 0) {
+            const int j = y / f;
+            if (t.j0 < 0)
+                t.j0 = j;
+            const T wa = axis == 0 ? ft.wy[a] : ft.wx[a];
+            if (j == t.j0)
+                t.w[0] += wa;
+            else
+                t.w[1] += wa;
+        }
+    }
+    if (t.j0 < 0)
+        t.j0 = 0;
+    tab[(size_t)k * len_pad + p] = t;
+}
+
+// BWD: hr = clip(hr + step * B'( crop P v ) / n),  v = sum_k F_k pad(U err_k) gathered per tile.
+// One block per T_HR x T_HR output tile.  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
+template <typename T, int L>
+__global__ void __launch_bounds__(256)
+    k_bwd_tile(const T *__restrict__ err, int h, int w, int N, const LTap<T> *__restrict__ tyT,
+               const LTap<T> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n, const T *__restrict__ hr_in,
+               T *__restrict__ hr_out)
+{
+    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 1;
+    constexpr int NRW = (BR + 3) / 4;
+    __shared__ T reg[BR * LD];
+    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
+    const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
+    const int nr = pb - pa, nc = qb - qa;
+    // ---- gather v into registers: this thread owns columns lane, lane+64 and rows wave, wave+4, ...
+    T acc[NRW][2];
+#pragma unroll
+    for (int m = 0; m < NRW; m++)
+        acc[m][0] = acc[m][1] = 0;
+    const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform: row taps come through scalar loads
+    for (int k = 0; k < N; k++) {
+        const T *e = err + ((size_t)b * N + k) * h * w;
+        const LTap<T> tx0 = txT[(size_t)k * Wp + qa + (c0ok ? lane : 0)];
+        const LTap<T> tx1 = txT[(size_t)k * Wp + qa + (c1ok ? lane + 64 : 0)];
+        const int x0b = min(tx0.j0 + 1, w - 1), x1b = min(tx1.j0 + 1, w - 1);
+        const LTap<T> *tyk = tyT + (size_t)k * Hp + pa;
+        // every load below is unconditional (rows past the region are clamped and dropped at the
+        // store): a guarded load would make hipcc branch and drain vmcnt per element
+#pragma unroll
+        for (int m = 0; m < NRW; m++) {
+            const int rr = min(uwave + 4 * m, nr - 1);
+            const LTap<T> ty = tyk[rr];
+            const T *ea = e + (size_t)ty.j0 * w;
+            if (L == 1) {
+                acc[m][0] += ty.w[0] * (tx0.w[0] * ea[tx0.j0]);
+                acc[m][1] += ty.w[0] * (tx1.w[0] * ea[tx1.j0]);
+            } else {
+                const T *eb = e + (size_t)min(ty.j0 + 1, h - 1) * w;
+                acc[m][0] += ty.w[0] * (tx0.w[0] * ea[tx0.j0] + tx0.w[1] * ea[x0b]) +
+                             ty.w[1] * (tx0.w[0] * eb[tx0.j0] + tx0.w[1] * eb[x0b]);
+                acc[m][1] += ty.w[0] * (tx1.w[0] * ea[tx1.j0] + tx1.w[1] * ea[x1b]) +
+                             ty.w[1] * (tx1.w[0] * eb[tx1.j0] + tx1.w[1] * eb[x1b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NRW; m++) {
+        const int rr = wave + 4 * m;
+        if (rr < nr) {
+            if (c0ok)
+                reg[rr * LD + lane] = acc[m][0];
+            if (c1ok)
+                reg[rr * LD + lane + 64] = acc[m][1];
+        }
+    }
+    __syncthreads();
+    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid);
+    // ---- B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
+    if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
+        for (int rr = wave; rr < nr; rr += 4) {
+            const int p = pa + rr;
+            const bool rout = p < SRX_NPAD || p >= H + SRX_NPAD;
+            for (int cc = lane; cc < nc; cc += 64) {
+                const int q = qa + cc;
+                if (rout || q < SRX_NPAD || q >= W + SRX_NPAD)
+                    reg[rr * LD + cc] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 7x7 correlation with the flipped kernel + update
+    const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
+    const int c = c0 + lane;
+    const size_t base = (size_t)b * H * W;
+#pragma unroll
+    for (int half = 0; half < TS / 32; half++) {
+        if (lane < TS) {
+            T a8[8];
+            corr7_strip8<T, LD>(win + half * 32 * LD, lane, wave, kt, a8);
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const int r = r0 + half * 32 + wave * 8 + o;
+                if (r < H && c < W) {
+                    const size_t i = base + (size_t)r * W + c;
+                    T v = hr_in[i] + step * a8[o] / n;
+                    hr_out[i] = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -329,7 +595,19 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
 {
     (void)f;
     const size_t padb = align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb);
-    return 2 * padb + align_up((size_t)B * N * h * w * eb);
+    return 2 * padb + align_up((size_t)B * N * h * w * eb) +
+           2 * align_up((size_t)N * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double>));
+}
+
+// SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
+static inline bool use_v1()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SRX_IBP_VARIANT");
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+    }
+    return v == 1;
 }
 
 template <typename T>
@@ -364,6 +642,32 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         return SRX_E_HIP;
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
+    if (f >= 2 && !use_v1()) {
+        // ---- v2: blur_pad -> fwd_tile -> bwd_tile ----
+        LTap<T> *tyT = ar.take<LTap<T>>((size_t)N * Hp), *txT = ar.take<LTap<T>>((size_t)N * Wp);
+        if (!ar.ok)
+            return SRX_E_WORKSPACE;
+        hipLaunchKernelGGL(k_build_ltaps<T>, dim3(cdiv(Hp, 64), N), dim3(64), 0, st, tyT, Hp, H, f, bwd, 0);
+        SRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_build_ltaps<T>, dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, f, bwd, 1);
+        SRX_CHECK_LAUNCH();
+        constexpr int TS = TileCfg<T>::T_HR;
+        const int tl = TS / f;  // LR tile edge
+        const dim3 fgrid(cdiv(w, tl), cdiv(h, tl), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
+        for (int it = 0; it < n_iter; it++) {
+            const T *cur = it == 0 ? hr_init : hr;
+            SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
+            SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
+                       omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
+            if (f == 4)
+                SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, 1>), wgrid, bblk, 0, st, err, h, w, N, tyT, txT, H, W, kt, (T)step,
+                           (T)N, cur, hr);
+            else
+                SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, 2>), wgrid, bblk, 0, st, err, h, w, N, tyT, txT, H, W, kt, (T)step,
+                           (T)N, cur, hr);
+        }
+        return SRX_OK;
+    }
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
         SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
