@@ -336,64 +336,48 @@ template <typename T> struct TileCfg;
 template <> struct TileCfg<float> { static constexpr int R = 12, T_HR = 64; };
 template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
 
-// in-place 2-D prefilter of an LDS region [nr x nc], row stride ld (odd: conflict-free row walks)
-template <typename T, int NT>
-__device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, int ld, bool top_edge, bool left_edge, int tid)
+// One line of the recursive prefilter on LDS (in place).  Measured: the tile kernels are bound by
+// instruction issue, not by this chain's latency (other waves fill the gaps), so the loop is kept
+// minimal -- an explicitly software-pipelined variant with clamped look-ahead reads was 10-15 % slower.
+template <typename T> __device__ __forceinline__ void line_iir(T *line, int n, int stride, bool edge)
 {
     const T z = pole<T>();
-    const T zfin = z / (z - (T)1);
     constexpr int K = Warmup<T>::n;
-    for (int c = tid; c < nc; c += NT) {  // axis 0: one thread per column
-        T *col = reg + c;
-        T prev = 0;
-        if (top_edge) {
-            T zi = 1, acc = 0;
-            const int kk = min(K, nr);
-            for (int i = 0; i < kk; i++) {
-                acc += zi * col[i * ld];
-                zi *= z;
-            }
-            prev = (T)6 * acc;  // c+[0] = 6 x[0] + z * sum_i z^i 6 x[i]   ('reflect' end)
+    T prev = 0;
+    if (edge) {  // exact 'reflect' end: c+[0] = 6 x[0] + z * sum_i z^i 6 x[i]
+        T zi = 1, acc = 0;
+        const int kk = min(K, n);
+        for (int i = 0; i < kk; i++) {
+            acc += zi * line[i * stride];
+            zi *= z;
         }
-#pragma unroll 4
-        for (int i = 0; i < nr; i++) {
-            prev = (T)6 * col[i * ld] + z * prev;
-            col[i * ld] = prev;
-        }
-        T next = prev * zfin;
-        col[(nr - 1) * ld] = next;
-#pragma unroll 4
-        for (int i = nr - 2; i >= 0; i--) {
-            next = z * (next - col[i * ld]);
-            col[i * ld] = next;
-        }
+        prev = (T)6 * acc;
     }
+#pragma unroll 4
+    for (int i = 0; i < n; i++) {
+        prev = (T)6 * line[i * stride] + z * prev;
+        line[i * stride] = prev;
+    }
+    T next = prev * (z / (z - (T)1));
+    line[(n - 1) * stride] = next;
+#pragma unroll 4
+    for (int i = n - 2; i >= 0; i--) {
+        next = z * (next - line[i * stride]);
+        line[i * stride] = next;
+    }
+}
+
+// in-place 2-D prefilter of an LDS region [nr x nc], row stride ld (odd: conflict-free row walks).
+// Axis 0 runs over all nc columns; axis 1 only over rows [r_lo, r_hi) (the rows a consumer reads).
+template <typename T, int NT>
+__device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, int ld, bool top_edge, bool left_edge, int tid,
+                                           int r_lo, int r_hi)
+{
+    for (int c = tid; c < nc; c += NT)
+        line_iir<T>(reg + c, nr, ld, top_edge);
     __syncthreads();
-    for (int r = tid; r < nr; r += NT) {  // axis 1: one thread per row
-        T *row = reg + r * ld;
-        T prev = 0;
-        if (left_edge) {
-            T zi = 1, acc = 0;
-            const int kk = min(K, nc);
-            for (int i = 0; i < kk; i++) {
-                acc += zi * row[i];
-                zi *= z;
-            }
-            prev = (T)6 * acc;
-        }
-#pragma unroll 4
-        for (int i = 0; i < nc; i++) {
-            prev = (T)6 * row[i] + z * prev;
-            row[i] = prev;
-        }
-        T next = prev * zfin;
-        row[nc - 1] = next;
-#pragma unroll 4
-        for (int i = nc - 2; i >= 0; i--) {
-            next = z * (next - row[i]);
-            row[i] = next;
-        }
-    }
+    for (int r = r_lo + tid; r < r_hi; r += NT)
+        line_iir<T>(reg + r * ld, nc, 1, left_edge);
     __syncthreads();
 }
 
@@ -419,7 +403,8 @@ __global__ void __launch_bounds__(256)
         for (int cc = lane; cc < nc; cc += 64)
             reg[rr * LD + cc] = src[(size_t)rr * Wp + cc];
     __syncthreads();
-    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid);
+    // rows the 4x4 taps of this tile's LR pixels read
+    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid, f * i0 + omin_y - pa, f * (i1 - 1) + omax_y + 4 - pa);
     const int N = fs.n;
     double sq = 0.0;
     for (int idx = tid; idx < th * tw; idx += 256) {
@@ -552,7 +537,8 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid);
+    // rows the 7x7 window of this tile reads: image rows [r0-3, r0+TS+3)
+    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid, r0 + 9 - pa, min(r0 + TS + 15, Hp) - pa);
     // ---- B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
     if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
         for (int rr = wave; rr < nr; rr += 4) {

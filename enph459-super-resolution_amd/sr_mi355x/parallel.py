@@ -1,0 +1,58 @@
+"""Multi-GPU sharding of independent work items (patches, sessions x reps).
+
+The reference processes its work items one after another in a single process
+(mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301); items never interact, so
+the path shards with NO data-path collective: item i goes to rank i mod G (the order the
+reference would reach it), every rank reconstructs its own items on its own GPU, and the
+uint8 / float results are gathered on the host of rank 0.  torch.distributed (RCCL = "nccl"
+on ROCm, "gloo" on CPU) is used only for that final gather and for barriers.
+"""
+import numpy as np
+
+
+def shard_indices(n_items, rank, world):
+    """Round-robin ownership: the items rank `rank` of `world` reconstructs."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_items, world))
+
+
+def owner_of(item, world):
+    return item % world
+
+
+def default_compute(lr, shifts_yx, kernel, factor, n_iter, step):
+    """One item on this rank's GPU through libsrx: SAA then IBP -> (hr float64 numpy, errors list)."""
+    from . import api
+    saa = api.shift_and_add(lr, shifts_yx, factor)
+    return api.ibp(lr, shifts_yx, kernel, saa, factor, n_iter, step, verbose=False)
+
+
+def reconstruct_sharded(items, shifts_yx, kernel, factor=2, n_iter=80, step=0.5, compute=None, group=None, dst=0):
+    """items: list of LR stacks [N, h, w] (every rank passes the same list; only owned ones are touched).
+
+    Returns, on rank `dst`, a list with one (hr, errors) per item in the original order; None elsewhere.
+    Without an initialised process group it just loops (world = 1).
+    """
+    import torch.distributed as dist
+    compute = compute or default_compute
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    mine = {}
+    for i in shard_indices(len(items), rank, world):
+        hr, errs = compute(items[i], shifts_yx, kernel, factor, n_iter, step)
+        mine[i] = (np.asarray(hr), [float(e) for e in errs])
+    if world == 1:
+        return [mine[i] for i in range(len(items))]
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(mine, gathered, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    if sorted(merged) != list(range(len(items))):
+        raise RuntimeError("sharding lost or duplicated items")
+    return [merged[i] for i in range(len(items))]
