@@ -438,55 +438,71 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&errors[(size_t)b * errors_stride], (part[0] + part[1] + part[2] + part[3]) * scale);
 }
 
-// Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= 2 LR samples
-// the 4-tap window of F_k touches (edge clamping merged in), so that
-//   v[p,q] = sum_k sum_{m,n<2} ty[k][p].w[m] tx[k][q].w[n] err_k[ty.j0+m][tx.j0+n]
-template <typename T> struct LTap {
-    int j0;
-    T w[2];
+// Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= L LR samples
+// (L = 1 for f = 4, 2 for f = 2, 3) the 4-tap window of F_k touches, edge clamping merged in:
+//   v[p,q] = sum_k sum_{m,n<L} row[p][k].w[m] col[k][q].w[n] err_b[row[p][k].o[m] + col[k][q].o[n]]
+// Row taps are laid out [p][KP] (KP = N rounded up to 8, padding frames have weight 0) so that one
+// wave-uniform s_load fetches the taps of 8 frames; their offsets already include the frame plane,
+// o = (k*h + jy)*w.  Column taps are laid out [k][q] for coalesced per-lane loads, o = jx.
+#define SRX_KCHUNK 8
+template <typename T, int L> struct LTap {
+    int o[L];
+    T w[L];
 };
 
-template <typename T>
+template <typename T, int L>
 __global__ void __launch_bounds__(64)
-    k_build_ltaps(LTap<T> *__restrict__ tab, int len_pad, int n_img, int f, FrameSet<T> fs, int axis)
+    k_build_ltaps(LTap<T, L> *__restrict__ tab, int len_pad, int n_img, int n_lr, int f, FrameSet<T> fs, int KP,
+                  int axis, int lr_w)
 {
     const int p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
     if (p >= len_pad)
         return;
-    const FrameTap<T> &ft = fs.f[k];
-    const int o = axis == 0 ? ft.oy : ft.ox;
-    LTap<T> t;
-    t.j0 = -1;
-    t.w[0] = t.w[1] = 0;
+    LTap<T, L> t;
+    int j0 = -1;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int y = min(max(p + o + a - SRX_NPAD, 0), n_img - 1);
-        if (y % f == 0) {
-            const int j = y / f;
-            if (t.j0 < 0)
-                t.j0 = j;
-            const T wa = axis == 0 ? ft.wy[a] : ft.wx[a];
-            if (j == t.j0)
-                t.w[0] += wa;
-            else
-                t.w[1] += wa;
+    for (int m = 0; m < L; m++)
+        t.w[m] = 0;
+    if (k < fs.n) {
+        const FrameTap<T> &ft = fs.f[k];
+        const int o = axis == 0 ? ft.oy : ft.ox;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int y = min(max(p + o + a - SRX_NPAD, 0), n_img - 1);
+            if (y % f == 0) {
+                const int j = y / f;
+                if (j0 < 0)
+                    j0 = j;
+                const T wa = axis == 0 ? ft.wy[a] : ft.wx[a];
+#pragma unroll
+                for (int m = 0; m < L; m++)
+                    if (j - j0 == m)
+                        t.w[m] += wa;
+            }
         }
     }
-    if (t.j0 < 0)
-        t.j0 = 0;
-    tab[(size_t)k * len_pad + p] = t;
+    if (j0 < 0)
+        j0 = 0;
+#pragma unroll
+    for (int m = 0; m < L; m++) {
+        const int j = min(j0 + m, n_lr - 1);  // a clamped slot always has weight 0
+        t.o[m] = axis == 0 ? (k * n_lr + j) * lr_w : j;
+    }
+    if (axis == 0)
+        tab[(size_t)p * KP + k] = t;
+    else
+        tab[(size_t)k * len_pad + p] = t;
 }
 
 // BWD: hr = clip(hr + step * B'( crop P v ) / n),  v = sum_k F_k pad(U err_k) gathered per tile.
 // One block per T_HR x T_HR output tile.  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
 template <typename T, int L>
 __global__ void __launch_bounds__(256)
-    k_bwd_tile(const T *__restrict__ err, int h, int w, int N, const LTap<T> *__restrict__ tyT,
-               const LTap<T> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n, const T *__restrict__ hr_in,
+    k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, L> *__restrict__ tyT,
+               const LTap<T, L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n, const T *__restrict__ hr_in,
                T *__restrict__ hr_out)
 {
     constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 1;
-    constexpr int NRW = (BR + 3) / 4;
     __shared__ T reg[BR * LD];
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
@@ -494,46 +510,50 @@ __global__ void __launch_bounds__(256)
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
     const int nr = pb - pa, nc = qb - qa;
-    // ---- gather v into registers: this thread owns columns lane, lane+64 and rows wave, wave+4, ...
-    T acc[NRW][2];
-#pragma unroll
-    for (int m = 0; m < NRW; m++)
-        acc[m][0] = acc[m][1] = 0;
+    // ---- gather v: this thread owns region columns lane and lane+64; its wave walks rows wave, wave+4, ...
+    // Frames go in chunks of 8: column taps of the chunk sit in registers, the row taps of a row come
+    // through one wave-uniform scalar load, the 16 residual loads of a row are issued back to back.
     const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform: row taps come through scalar loads
-    for (int k = 0; k < N; k++) {
-        const T *e = err + ((size_t)b * N + k) * h * w;
-        const LTap<T> tx0 = txT[(size_t)k * Wp + qa + (c0ok ? lane : 0)];
-        const LTap<T> tx1 = txT[(size_t)k * Wp + qa + (c1ok ? lane + 64 : 0)];
-        const int x0b = min(tx0.j0 + 1, w - 1), x1b = min(tx1.j0 + 1, w - 1);
-        const LTap<T> *tyk = tyT + (size_t)k * Hp + pa;
-        // every load below is unconditional (rows past the region are clamped and dropped at the
-        // store): a guarded load would make hipcc branch and drain vmcnt per element
+    const int q0 = qa + (c0ok ? lane : 0), q1 = qa + (c1ok ? lane + 64 : 0);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const T *eb = err + (size_t)b * N * h * w;
+    for (int kc = 0; kc < KP; kc += SRX_KCHUNK) {
+        LTap<T, L> cx0[SRX_KCHUNK], cx1[SRX_KCHUNK];
 #pragma unroll
-        for (int m = 0; m < NRW; m++) {
-            const int rr = min(uwave + 4 * m, nr - 1);
-            const LTap<T> ty = tyk[rr];
-            const T *ea = e + (size_t)ty.j0 * w;
-            if (L == 1) {
-                acc[m][0] += ty.w[0] * (tx0.w[0] * ea[tx0.j0]);
-                acc[m][1] += ty.w[0] * (tx1.w[0] * ea[tx1.j0]);
-            } else {
-                const T *eb = e + (size_t)min(ty.j0 + 1, h - 1) * w;
-                acc[m][0] += ty.w[0] * (tx0.w[0] * ea[tx0.j0] + tx0.w[1] * ea[x0b]) +
-                             ty.w[1] * (tx0.w[0] * eb[tx0.j0] + tx0.w[1] * eb[x0b]);
-                acc[m][1] += ty.w[0] * (tx1.w[0] * ea[tx1.j0] + tx1.w[1] * ea[x1b]) +
-                             ty.w[1] * (tx1.w[0] * eb[tx1.j0] + tx1.w[1] * eb[x1b]);
-            }
+        for (int k = 0; k < SRX_KCHUNK; k++) {
+            const int kk = min(kc + k, N - 1);  // padding frames: any valid column tap, their row weight is 0
+            cx0[k] = txT[(size_t)kk * Wp + q0];
+            cx1[k] = txT[(size_t)kk * Wp + q1];
         }
-    }
+        for (int rr = uwave; rr < nr; rr += 4) {
+            const LTap<T, L> *trow = tyT + (size_t)(pa + rr) * KP + kc;
+            T a0 = 0, a1 = 0;
 #pragma unroll
-    for (int m = 0; m < NRW; m++) {
-        const int rr = wave + 4 * m;
-        if (rr < nr) {
-            if (c0ok)
-                reg[rr * LD + lane] = acc[m][0];
-            if (c1ok)
-                reg[rr * LD + lane + 64] = acc[m][1];
+            for (int k = 0; k < SRX_KCHUNK; k++) {
+                const LTap<T, L> ty = trow[k];
+#pragma unroll
+                for (int m = 0; m < L; m++) {
+                    T s0 = 0, s1 = 0;
+#pragma unroll
+                    for (int q = 0; q < L; q++) {
+                        s0 += cx0[k].w[q] * eb[(unsigned)(ty.o[m] + cx0[k].o[q])];
+                        s1 += cx1[k].w[q] * eb[(unsigned)(ty.o[m] + cx1[k].o[q])];
+                    }
+                    a0 += ty.w[m] * s0;
+                    a1 += ty.w[m] * s1;
+                }
+            }
+            if (kc == 0) {
+                if (c0ok)
+                    reg[rr * LD + lane] = a0;
+                if (c1ok)
+                    reg[rr * LD + lane + 64] = a1;
+            } else {
+                if (c0ok)
+                    reg[rr * LD + lane] += a0;
+                if (c1ok)
+                    reg[rr * LD + lane + 64] += a1;
+            }
         }
     }
     __syncthreads();
@@ -582,7 +602,7 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
     (void)f;
     const size_t padb = align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb);
     return 2 * padb + align_up((size_t)B * N * h * w * eb) +
-           2 * align_up((size_t)N * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double>));
+           2 * align_up((size_t)(N + SRX_KCHUNK) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>));
 }
 
 // SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
@@ -594,6 +614,37 @@ static inline bool use_v1()
         v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
     }
     return v == 1;
+}
+
+// v2 iteration loop: blur_pad -> fwd_tile -> bwd_tile, lattice-tap tables built once per call
+template <typename T, int L>
+static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, int f, const FrameSet<T> &fwd, const FrameSet<T> &bwd,
+                       int omin_y, int omax_y, int omin_x, int omax_x, const Kernel7<T> &kc, const Kernel7<T> &kt,
+                       const T *hr_init, int H, int W, int n_iter, double step, T *hr, double *errors, double scale,
+                       T *pad, T *err, Arena &ar, hipStream_t st)
+{
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    const int KP = (N + SRX_KCHUNK - 1) / SRX_KCHUNK * SRX_KCHUNK;
+    LTap<T, L> *tyT = ar.take<LTap<T, L>>((size_t)KP * Hp), *txT = ar.take<LTap<T, L>>((size_t)N * Wp);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Hp, 64), KP), dim3(64), 0, st, tyT, Hp, H, h, f, bwd, KP, 0, w);
+    SRX_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, w, f, bwd, KP, 1, w);
+    SRX_CHECK_LAUNCH();
+    constexpr int TS = TileCfg<T>::T_HR;
+    const int tl = TS / f;  // LR tile edge
+    const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
+    const dim3 fgrid(cdiv(w, tl), cdiv(h, tl), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
+    for (int it = 0; it < n_iter; it++) {
+        const T *cur = it == 0 ? hr_init : hr;
+        SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
+                   omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
+        SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
+                   (T)N, cur, hr);
+    }
+    return SRX_OK;
 }
 
 template <typename T>
@@ -630,29 +681,11 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     if (f >= 2 && !use_v1()) {
         // ---- v2: blur_pad -> fwd_tile -> bwd_tile ----
-        LTap<T> *tyT = ar.take<LTap<T>>((size_t)N * Hp), *txT = ar.take<LTap<T>>((size_t)N * Wp);
-        if (!ar.ok)
-            return SRX_E_WORKSPACE;
-        hipLaunchKernelGGL(k_build_ltaps<T>, dim3(cdiv(Hp, 64), N), dim3(64), 0, st, tyT, Hp, H, f, bwd, 0);
-        SRX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_build_ltaps<T>, dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, f, bwd, 1);
-        SRX_CHECK_LAUNCH();
-        constexpr int TS = TileCfg<T>::T_HR;
-        const int tl = TS / f;  // LR tile edge
-        const dim3 fgrid(cdiv(w, tl), cdiv(h, tl), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
-        for (int it = 0; it < n_iter; it++) {
-            const T *cur = it == 0 ? hr_init : hr;
-            SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
-            SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
-                       omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
-            if (f == 4)
-                SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, 1>), wgrid, bblk, 0, st, err, h, w, N, tyT, txT, H, W, kt, (T)step,
-                           (T)N, cur, hr);
-            else
-                SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, 2>), wgrid, bblk, 0, st, err, h, w, N, tyT, txT, H, W, kt, (T)step,
-                           (T)N, cur, hr);
-        }
-        return SRX_OK;
+        if (f == 4)
+            return ibp_v2_loop<T, 1>(lr, B, N, h, w, f, fwd, bwd, omin_y, omax_y, omin_x, omax_x, kc, kt, hr_init, H, W,
+                                     n_iter, step, hr, errors, scale, pad, err, ar, st);
+        return ibp_v2_loop<T, 2>(lr, B, N, h, w, f, fwd, bwd, omin_y, omax_y, omin_x, omax_x, kc, kt, hr_init, H, W,
+                                 n_iter, step, hr, errors, scale, pad, err, ar, st);
     }
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
