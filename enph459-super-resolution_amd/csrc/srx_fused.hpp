@@ -37,7 +37,9 @@ template <typename T> struct FrameSet {
     FrameTap<T> f[SRX_MAX_FRAMES];
 };
 template <typename T> struct Kernel7 {
-    T k[49];  // correlation weights: out[i,j] = sum_{u,v} in[i-3+u, j-3+v] k[u*7+v]
+    T k[49];         // correlation weights: out[i,j] = sum_{u,v} in[i-3+u, j-3+v] k[u*7+v]
+    T cy[7], cx[7];  // if the PSF is rank 1 (the reference's default Gaussian): k[u*7+v] = cy[u] * cx[v]
+    int separable;
 };
 
 static inline void host_weights(double t, double w[4])
@@ -77,6 +79,30 @@ template <typename T> static void make_kernel7(const double *k, int kh, int kw, 
             const double v = flip ? k[(kh - 1 - m) * kw + (kw - 1 - n)] : k[m * kw + n];
             out.k[(py + kh - 1 - m) * 7 + (px + kw - 1 - n)] = (T)v;
         }
+    // rank-1 test in float64 on the embedded 7x7 weights: c = col * row^T through the largest entry.
+    // exp(-(x^2+y^2)/2s^2) vs exp(-x^2/2s^2) exp(-y^2/2s^2) differ by ~1 ulp, hence the 8-ulp allowance;
+    // the separable evaluation then differs from the 49-tap sum by ~1e-15 relative (summation order).
+    double c[49], amax = 0.0;
+    int um = 0, vm = 0;
+    for (int i = 0; i < 49; i++)
+        c[i] = 0.0;
+    for (int m = 0; m < kh; m++)
+        for (int n = 0; n < kw; n++)
+            c[(py + kh - 1 - m) * 7 + (px + kw - 1 - n)] = flip ? k[(kh - 1 - m) * kw + (kw - 1 - n)] : k[m * kw + n];
+    for (int i = 0; i < 49; i++)
+        if (std::fabs(c[i]) > amax)
+            amax = std::fabs(c[i]), um = i / 7, vm = i % 7;
+    bool sep = amax > 0.0 && !getenv("SRX_NO_SEPARABLE");
+    double dev = 0.0;
+    for (int u = 0; u < 7 && sep; u++)
+        for (int v = 0; v < 7; v++)
+            dev = std::max(dev, std::fabs(c[u * 7 + v] - c[u * 7 + vm] * (c[um * 7 + v] / c[um * 7 + vm])));
+    sep = sep && dev <= 8 * 2.220446049250313e-16 * amax;
+    out.separable = sep ? 1 : 0;
+    for (int u = 0; u < 7; u++) {
+        out.cy[u] = sep ? (T)c[u * 7 + vm] : (T)0;
+        out.cx[u] = sep ? (T)(c[um * 7 + u] / c[um * 7 + vm]) : (T)0;
+    }
 }
 
 static inline bool shifts_ok(int N, const double *sh, int f)
@@ -107,33 +133,52 @@ static inline bool saa_eligible(int N, int h, int w, const double *sh, int f)
 #define SRX_BT_H 32
 #define SRX_BT_LDW 72
 
-template <typename T, int LDW = SRX_BT_LDW>
+template <typename T, int LDW = SRX_BT_LDW, bool SEP = false>
 __device__ __forceinline__ void corr7_strip8(const T *tile, int tx, int ty, const Kernel7<T> &ka, T acc[8])
 {
 #pragma unroll
     for (int o = 0; o < 8; o++)
         acc[o] = 0;
+    if constexpr (SEP) {
+        // rank-1 PSF: 7-tap row sums of the 14 source rows (98 FMA), then 7-tap column sums (56 FMA)
+        T hrow[14];
 #pragma unroll
-    for (int sr = 0; sr < 14; sr++) {
-        T v[7];
-        const T *row = tile + (ty * 8 + sr) * LDW + tx;
+        for (int sr = 0; sr < 14; sr++) {
+            const T *row = tile + (ty * 8 + sr) * LDW + tx;
+            T a = 0;
 #pragma unroll
-        for (int n = 0; n < 7; n++)
-            v[n] = row[n];
+            for (int n = 0; n < 7; n++)
+                a += row[n] * ka.cx[n];
+            hrow[sr] = a;
+        }
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
-            const int u = sr - o;
-            if (u >= 0 && u < 7) {
+        for (int o = 0; o < 8; o++)
 #pragma unroll
-                for (int n = 0; n < 7; n++)
-                    acc[o] += v[n] * ka.k[u * 7 + n];
+            for (int u = 0; u < 7; u++)
+                acc[o] += ka.cy[u] * hrow[o + u];
+    } else {
+#pragma unroll
+        for (int sr = 0; sr < 14; sr++) {
+            T v[7];
+            const T *row = tile + (ty * 8 + sr) * LDW + tx;
+#pragma unroll
+            for (int n = 0; n < 7; n++)
+                v[n] = row[n];
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const int u = sr - o;
+                if (u >= 0 && u < 7) {
+#pragma unroll
+                    for (int n = 0; n < 7; n++)
+                        acc[o] += v[n] * ka.k[u * 7 + n];
+                }
             }
         }
     }
 }
 
 // K_A: bpad = pad12_edge(B hr).  grid (ceil(W/64), ceil(H/32), B), block (64, 4).
-template <typename T>
+template <typename T, bool SEP>
 __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int H, int W, Kernel7<T> ka, T *__restrict__ bpad)
 {
     __shared__ T tile[(SRX_BT_H + 6) * SRX_BT_LDW];
@@ -147,7 +192,7 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     }
     __syncthreads();
     T acc[8];
-    corr7_strip8(tile, tx, ty, ka, acc);
+    corr7_strip8<T, SRX_BT_LDW, SEP>(tile, tx, ty, ka, acc);
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     T *dst = bpad + (size_t)blockIdx.z * Hp * Wp;
     const int c = c0 + tx;
@@ -167,7 +212,7 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
 }
 
 // K_C: hr = clip(hr + step * (B' g) / n, 0, 255), g = crop(vpad) (zero outside the image).
-template <typename T>
+template <typename T, bool SEP>
 __global__ void __launch_bounds__(256)
     k_blurT_update(const T *__restrict__ vpad, int H, int W, Kernel7<T> ka, T step, T n, const T *__restrict__ hr_in,
                    T *__restrict__ hr_out)
@@ -185,7 +230,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     T acc[8];
-    corr7_strip8(tile, tx, ty, ka, acc);
+    corr7_strip8<T, SRX_BT_LDW, SEP>(tile, tx, ty, ka, acc);
     const int c = c0 + tx;
     if (c >= W)
         return;
@@ -494,9 +539,19 @@ __global__ void __launch_bounds__(64)
         tab[(size_t)k * len_pad + p] = t;
 }
 
+template <typename T> __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff);
+template <> __device__ __forceinline__ float buf_load<float>(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+
 // BWD: hr = clip(hr + step * B'( crop P v ) / n),  v = sum_k F_k pad(U err_k) gathered per tile.
 // One block per T_HR x T_HR output tile.  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
-template <typename T, int L>
+template <typename T, int L, bool SEP>
 __global__ void __launch_bounds__(256)
     k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, L> *__restrict__ tyT,
                const LTap<T, L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n, const T *__restrict__ hr_in,
@@ -516,43 +571,69 @@ __global__ void __launch_bounds__(256)
     const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
     const int q0 = qa + (c0ok ? lane : 0), q1 = qa + (c1ok ? lane + 64 : 0);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    // residuals of this item through a buffer descriptor: address = base + voffset(column tap, VGPR)
+    // + soffset(row tap, SGPR) -- no per-load address arithmetic; out-of-range reads return 0
     const T *eb = err + (size_t)b * N * h * w;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)eb, 0, (int)((size_t)N * h * w * sizeof(T)), 0x00020000);
     for (int kc = 0; kc < KP; kc += SRX_KCHUNK) {
-        LTap<T, L> cx0[SRX_KCHUNK], cx1[SRX_KCHUNK];
+        T cw0[SRX_KCHUNK][L], cw1[SRX_KCHUNK][L];
+        int co0[SRX_KCHUNK][L], co1[SRX_KCHUNK][L];
 #pragma unroll
         for (int k = 0; k < SRX_KCHUNK; k++) {
             const int kk = min(kc + k, N - 1);  // padding frames: any valid column tap, their row weight is 0
-            cx0[k] = txT[(size_t)kk * Wp + q0];
-            cx1[k] = txT[(size_t)kk * Wp + q1];
+            const LTap<T, L> t0 = txT[(size_t)kk * Wp + q0], t1 = txT[(size_t)kk * Wp + q1];
+#pragma unroll
+            for (int q = 0; q < L; q++) {
+                cw0[k][q] = t0.w[q], cw1[k][q] = t1.w[q];
+                co0[k][q] = t0.o[q] * (int)sizeof(T), co1[k][q] = t1.o[q] * (int)sizeof(T);
+            }
         }
-        for (int rr = uwave; rr < nr; rr += 4) {
+        // two region rows per trip: 2 x 16 residual loads in flight per lane before the first use
+        for (int rr = uwave; rr < nr; rr += 8) {
+            const int rr2 = min(rr + 4, nr - 1);  // clamped duplicate when the tile has no second row; dropped below
             const LTap<T, L> *trow = tyT + (size_t)(pa + rr) * KP + kc;
-            T a0 = 0, a1 = 0;
+            const LTap<T, L> *trow2 = tyT + (size_t)(pa + rr2) * KP + kc;
+            T a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 #pragma unroll
             for (int k = 0; k < SRX_KCHUNK; k++) {
-                const LTap<T, L> ty = trow[k];
+                const LTap<T, L> ty = trow[k], ty2 = trow2[k];
 #pragma unroll
                 for (int m = 0; m < L; m++) {
-                    T s0 = 0, s1 = 0;
+                    const int so = ty.o[m] * (int)sizeof(T), so2 = ty2.o[m] * (int)sizeof(T);
+                    T s0 = 0, s1 = 0, u0 = 0, u1 = 0;
 #pragma unroll
                     for (int q = 0; q < L; q++) {
-                        s0 += cx0[k].w[q] * eb[(unsigned)(ty.o[m] + cx0[k].o[q])];
-                        s1 += cx1[k].w[q] * eb[(unsigned)(ty.o[m] + cx1[k].o[q])];
+                        s0 += cw0[k][q] * buf_load<T>(rs, co0[k][q], so);
+                        s1 += cw1[k][q] * buf_load<T>(rs, co1[k][q], so);
+                        u0 += cw0[k][q] * buf_load<T>(rs, co0[k][q], so2);
+                        u1 += cw1[k][q] * buf_load<T>(rs, co1[k][q], so2);
                     }
                     a0 += ty.w[m] * s0;
                     a1 += ty.w[m] * s1;
+                    b0 += ty2.w[m] * u0;
+                    b1 += ty2.w[m] * u1;
                 }
             }
+            const bool second = rr + 4 < nr;
             if (kc == 0) {
                 if (c0ok)
                     reg[rr * LD + lane] = a0;
                 if (c1ok)
                     reg[rr * LD + lane + 64] = a1;
+                if (second && c0ok)
+                    reg[rr2 * LD + lane] = b0;
+                if (second && c1ok)
+                    reg[rr2 * LD + lane + 64] = b1;
             } else {
                 if (c0ok)
                     reg[rr * LD + lane] += a0;
                 if (c1ok)
                     reg[rr * LD + lane + 64] += a1;
+                if (second && c0ok)
+                    reg[rr2 * LD + lane] += b0;
+                if (second && c1ok)
+                    reg[rr2 * LD + lane + 64] += b1;
             }
         }
     }
@@ -580,7 +661,7 @@ __global__ void __launch_bounds__(256)
     for (int half = 0; half < TS / 32; half++) {
         if (lane < TS) {
             T a8[8];
-            corr7_strip8<T, LD>(win + half * 32 * LD, lane, wave, kt, a8);
+            corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
 #pragma unroll
             for (int o = 0; o < 8; o++) {
                 const int r = r0 + half * 32 + wave * 8 + o;
@@ -634,15 +715,23 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, int f, const Fra
     SRX_CHECK_LAUNCH();
     constexpr int TS = TileCfg<T>::T_HR;
     const int tl = TS / f;  // LR tile edge
+    const bool sep = kc.separable && kt.separable;
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     const dim3 fgrid(cdiv(w, tl), cdiv(h, tl), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
-        SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        if (sep)
+            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, true>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        else
+            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
                    omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
-        SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
-                   (T)N, cur, hr);
+        if (sep)
+            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
+                       (T)step, (T)N, cur, hr);
+        else
+            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
+                       (T)step, (T)N, cur, hr);
     }
     return SRX_OK;
 }
@@ -689,7 +778,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     }
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
-        SRX_LAUNCH(KID_BLUR_PAD, k_blur_pad<T>, bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
         SRX_LAUNCH(KID_FWD_RESIDUAL, k_fwd_residual<T>, dim3(cdiv(w, 16), cdiv(h, 16), B), dim3(16, 16),
                    (size_t)th * tw * sizeof(T), st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omin_x, th, tw, err,
@@ -697,7 +786,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         SRX_LAUNCH(KID_BACK_GATHER, k_back_gather<T>, dim3(cdiv(Wp, 64), cdiv(Hp, 4), B), dim3(64, 4), 0, st, err, h, w, f,
                    bwd, H, W, pad);
         SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
-        SRX_LAUNCH(KID_BLURT_UPDATE, k_blurT_update<T>, bgrid, bblk, 0, st, pad, H, W, kt, (T)step, (T)N, cur, hr);
+        SRX_LAUNCH(KID_BLURT_UPDATE, (k_blurT_update<T, false>), bgrid, bblk, 0, st, pad, H, W, kt, (T)step, (T)N, cur, hr);
     }
     return SRX_OK;
 }
