@@ -487,8 +487,8 @@ __global__ void __launch_bounds__(256)
 // (L = 1 for f = 4, 2 for f = 2, 3) the 4-tap window of F_k touches, edge clamping merged in:
 //   v[p,q] = sum_k sum_{m,n<L} row[p][k].w[m] col[k][q].w[n] err_b[row[p][k].o[m] + col[k][q].o[n]]
 // Row taps are laid out [p][KP] (KP = N rounded up to 8, padding frames have weight 0) so that one
-// wave-uniform s_load fetches the taps of 8 frames; their offsets already include the frame plane,
-// o = (k*h + jy)*w.  Column taps are laid out [k][q] for coalesced per-lane loads, o = jx.
+// wave-uniform s_load fetches the taps of a chunk of frames; o = LR row index jy.  Column taps are laid
+// out [k][q] for coalesced per-lane loads, o = LR column index jx.
 #define SRX_KCHUNK 8
 template <typename T, int L> struct LTap {
     int o[L];
@@ -498,7 +498,7 @@ template <typename T, int L> struct LTap {
 template <typename T, int L>
 __global__ void __launch_bounds__(64)
     k_build_ltaps(LTap<T, L> *__restrict__ tab, int len_pad, int n_img, int n_lr, int f, FrameSet<T> fs, int KP,
-                  int axis, int lr_w)
+                  int axis)
 {
     const int p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
     if (p >= len_pad)
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
     for (int m = 0; m < L; m++) {
         const int j = min(j0 + m, n_lr - 1);  // a clamped slot always has weight 0
-        t.o[m] = axis == 0 ? (k * n_lr + j) * lr_w : j;
+        t.o[m] = j;
     }
     if (axis == 0)
         tab[(size_t)p * KP + k] = t;
@@ -551,13 +551,24 @@ template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_r
 
 // BWD: hr = clip(hr + step * B'( crop P v ) / n),  v = sum_k F_k pad(U err_k) gathered per tile.
 // One block per T_HR x T_HR output tile.  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
-template <typename T, int L, bool SEP>
+// The gather runs over chunks of KS frames and reads the residuals from L1/L2 through a buffer
+// descriptor: address = base + voffset (column tap, VGPR) + soffset (row tap, SGPR), no per-load
+// address arithmetic.  (Measured alternative, dropped: staging each chunk's residual patch in LDS first
+// -- 61 KB of LDS, 2 blocks per CU, 4 more barriers -- ran 1.7x slower than this.)
+template <typename T, int F> struct BwdCfg {
+    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R;
+    static constexpr int KS = F >= 4 ? 8 : (F == 3 ? 4 : 2);          // frames per chunk
+    static constexpr int L = F >= 4 ? 1 : 2;                          // lattice taps per axis
+};
+
+template <typename T, int F, bool SEP>
 __global__ void __launch_bounds__(256)
-    k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, L> *__restrict__ tyT,
-               const LTap<T, L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n, const T *__restrict__ hr_in,
-               T *__restrict__ hr_out)
+    k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, BwdCfg<T, F>::L> *__restrict__ tyT,
+               const LTap<T, BwdCfg<T, F>::L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n,
+               const T *__restrict__ hr_in, T *__restrict__ hr_out)
 {
-    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 1;
+    using C = BwdCfg<T, F>;
+    constexpr int R = C::R, TS = C::TS, BR = C::BR, LD = BR + 1, L = C::L, KS = C::KS;
     __shared__ T reg[BR * LD];
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
@@ -566,42 +577,40 @@ __global__ void __launch_bounds__(256)
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
     const int nr = pb - pa, nc = qb - qa;
     // ---- gather v: this thread owns region columns lane and lane+64; its wave walks rows wave, wave+4, ...
-    // Frames go in chunks of 8: column taps of the chunk sit in registers, the row taps of a row come
-    // through one wave-uniform scalar load, the 16 residual loads of a row are issued back to back.
     const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
     const int q0 = qa + (c0ok ? lane : 0), q1 = qa + (c1ok ? lane + 64 : 0);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    // residuals of this item through a buffer descriptor: address = base + voffset(column tap, VGPR)
-    // + soffset(row tap, SGPR) -- no per-load address arithmetic; out-of-range reads return 0
     const T *eb = err + (size_t)b * N * h * w;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc((void *)eb, 0, (int)((size_t)N * h * w * sizeof(T)), 0x00020000);
-    for (int kc = 0; kc < KP; kc += SRX_KCHUNK) {
-        T cw0[SRX_KCHUNK][L], cw1[SRX_KCHUNK][L];
-        int co0[SRX_KCHUNK][L], co1[SRX_KCHUNK][L];
+    for (int kc = 0; kc < KP; kc += KS) {
+        T cw0[KS][L], cw1[KS][L];
+        int co0[KS][L], co1[KS][L];
 #pragma unroll
-        for (int k = 0; k < SRX_KCHUNK; k++) {
+        for (int k = 0; k < KS; k++) {
             const int kk = min(kc + k, N - 1);  // padding frames: any valid column tap, their row weight is 0
             const LTap<T, L> t0 = txT[(size_t)kk * Wp + q0], t1 = txT[(size_t)kk * Wp + q1];
 #pragma unroll
             for (int q = 0; q < L; q++) {
                 cw0[k][q] = t0.w[q], cw1[k][q] = t1.w[q];
-                co0[k][q] = t0.o[q] * (int)sizeof(T), co1[k][q] = t1.o[q] * (int)sizeof(T);
+                co0[k][q] = t0.o[q] * (int)sizeof(T);
+                co1[k][q] = t1.o[q] * (int)sizeof(T);
             }
         }
-        // two region rows per trip: 2 x 16 residual loads in flight per lane before the first use
+        // two region rows per trip: 2 x 2 x KS residual reads in flight per lane before the first use
         for (int rr = uwave; rr < nr; rr += 8) {
-            const int rr2 = min(rr + 4, nr - 1);  // clamped duplicate when the tile has no second row; dropped below
+            const int rr2 = min(rr + 4, nr - 1);  // clamped duplicate when there is no second row; dropped below
             const LTap<T, L> *trow = tyT + (size_t)(pa + rr) * KP + kc;
             const LTap<T, L> *trow2 = tyT + (size_t)(pa + rr2) * KP + kc;
             T a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 #pragma unroll
-            for (int k = 0; k < SRX_KCHUNK; k++) {
+            for (int k = 0; k < KS; k++) {
                 const LTap<T, L> ty = trow[k], ty2 = trow2[k];
 #pragma unroll
                 for (int m = 0; m < L; m++) {
-                    const int so = ty.o[m] * (int)sizeof(T), so2 = ty2.o[m] * (int)sizeof(T);
                     T s0 = 0, s1 = 0, u0 = 0, u1 = 0;
+                    const int so = (min(kc + k, N - 1) * h + ty.o[m]) * w * (int)sizeof(T);
+                    const int so2 = (min(kc + k, N - 1) * h + ty2.o[m]) * w * (int)sizeof(T);
 #pragma unroll
                     for (int q = 0; q < L; q++) {
                         s0 += cw0[k][q] * buf_load<T>(rs, co0[k][q], so);
@@ -683,7 +692,7 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
     (void)f;
     const size_t padb = align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb);
     return 2 * padb + align_up((size_t)B * N * h * w * eb) +
-           2 * align_up((size_t)(N + SRX_KCHUNK) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>));
+           2 * align_up((size_t)(N + 8) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>));
 }
 
 // SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
@@ -698,20 +707,22 @@ static inline bool use_v1()
 }
 
 // v2 iteration loop: blur_pad -> fwd_tile -> bwd_tile, lattice-tap tables built once per call
-template <typename T, int L>
-static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, int f, const FrameSet<T> &fwd, const FrameSet<T> &bwd,
+template <typename T, int F>
+static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T> &fwd, const FrameSet<T> &bwd,
                        int omin_y, int omax_y, int omin_x, int omax_x, const Kernel7<T> &kc, const Kernel7<T> &kt,
                        const T *hr_init, int H, int W, int n_iter, double step, T *hr, double *errors, double scale,
                        T *pad, T *err, Arena &ar, hipStream_t st)
 {
+    using C = BwdCfg<T, F>;
+    constexpr int L = C::L, KS = C::KS, f = F;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    const int KP = (N + SRX_KCHUNK - 1) / SRX_KCHUNK * SRX_KCHUNK;
+    const int KP = (N + KS - 1) / KS * KS;
     LTap<T, L> *tyT = ar.take<LTap<T, L>>((size_t)KP * Hp), *txT = ar.take<LTap<T, L>>((size_t)N * Wp);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Hp, 64), KP), dim3(64), 0, st, tyT, Hp, H, h, f, bwd, KP, 0, w);
+    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Hp, 64), KP), dim3(64), 0, st, tyT, Hp, H, h, f, bwd, KP, 0);
     SRX_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, w, f, bwd, KP, 1, w);
+    hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, w, f, bwd, KP, 1);
     SRX_CHECK_LAUNCH();
     constexpr int TS = TileCfg<T>::T_HR;
     const int tl = TS / f;  // LR tile edge
@@ -726,11 +737,11 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, int f, const Fra
             SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
                    omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
-        if (sep)
-            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
-                       (T)step, (T)N, cur, hr);
+if (sep)
+            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
+                       (T)N, cur, hr);
         else
-            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, L, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
+            SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
                        (T)step, (T)N, cur, hr);
     }
     return SRX_OK;
@@ -770,11 +781,15 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     if (f >= 2 && !use_v1()) {
         // ---- v2: blur_pad -> fwd_tile -> bwd_tile ----
+#define SRX_V2(FF)                                                                                                  \
+    return ibp_v2_loop<T, FF>(lr, B, N, h, w, fwd, bwd, omin_y, omax_y, omin_x, omax_x, kc, kt, hr_init, H, W, n_iter, \
+                              step, hr, errors, scale, pad, err, ar, st)
         if (f == 4)
-            return ibp_v2_loop<T, 1>(lr, B, N, h, w, f, fwd, bwd, omin_y, omax_y, omin_x, omax_x, kc, kt, hr_init, H, W,
-                                     n_iter, step, hr, errors, scale, pad, err, ar, st);
-        return ibp_v2_loop<T, 2>(lr, B, N, h, w, f, fwd, bwd, omin_y, omax_y, omin_x, omax_x, kc, kt, hr_init, H, W,
-                                 n_iter, step, hr, errors, scale, pad, err, ar, st);
+            SRX_V2(4);
+        if (f == 3)
+            SRX_V2(3);
+        SRX_V2(2);
+#undef SRX_V2
     }
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
