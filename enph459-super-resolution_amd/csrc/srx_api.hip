@@ -6,6 +6,7 @@
 
 #include "srx_prims.hpp"
 #include "srx_fused.hpp"
+#include "srx_mosaic.hpp"
 
 using namespace srx;
 
@@ -21,7 +22,8 @@ Profiler &profiler()
 
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
-    "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile"};
+    "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -297,6 +299,10 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
     if ((flags & SRX_FLAG_FUSED) && !can_fuse)
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
+        if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
+            g_last_path = "mosaic";
+            return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
+        }
         g_last_path = "fused";
         return fused::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
     }
@@ -389,6 +395,8 @@ size_t srx_saa_workspace_bytes(int eb, int B, int N, int h, int w, int f)
 size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W, int f, unsigned flags)
 {
     size_t a = ibp_ws_composed(eb, B, N, h, w, H, W, f), b = fused::ibp_ws(eb, B, N, h, w, H, W, f);
+    const size_t c = mosaic::ibp_ws(eb, B, N, H, W);
+    b = b > c ? b : c;
     if (flags & SRX_FLAG_FUSED)
         return b;
     if (flags & SRX_FLAG_COMPOSED)

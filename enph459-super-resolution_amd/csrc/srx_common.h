@@ -62,6 +62,9 @@ enum KernelId {
     KID_CROP_DIV,
     KID_FWD_TILE,
     KID_BWD_TILE,
+    KID_MOSAIC_BUILD,
+    KID_FWD_MOSAIC,
+    KID_BWD_MOSAIC,
     KID_COUNT
 };
 

@@ -177,6 +177,36 @@ __device__ __forceinline__ void corr7_strip8(const T *tile, int tx, int ty, cons
     }
 }
 
+// Copy a region [nr x nc] (nr <= MAXR, nc <= MAXC) of a row-major plane into LDS, 256 threads as 4 waves
+// of 64 lanes: wave w takes rows w, w+4, ...; lanes take columns.  Loads are issued in batches of 8 rows
+// before the first LDS store, from clamped (always valid) addresses -- a per-element guarded load makes
+// hipcc wait for each load in turn, which was the single largest cost of the first tile kernels.
+template <typename T, int MAXR, int MAXC>
+__device__ __forceinline__ void load_region(T *__restrict__ reg, int ld, const T *__restrict__ src, size_t pitch, int nr,
+                                            int nc, int wave, int lane)
+{
+    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64, BATCH = 8;
+#pragma unroll
+    for (int j0 = 0; j0 < RPW; j0 += BATCH) {
+        T v[BATCH][CPL];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int rr = min(wave + 4 * (j0 + j), nr - 1);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                v[j][cc] = src[(size_t)rr * pitch + min(lane + 64 * cc, nc - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int rr = wave + 4 * (j0 + j);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                if (rr < nr && lane + 64 * cc < nc)
+                    reg[rr * ld + lane + 64 * cc] = v[j][cc];
+        }
+    }
+}
+
 // K_A: bpad = pad12_edge(B hr).  grid (ceil(W/64), ceil(H/32), B), block (64, 4).
 template <typename T, bool SEP>
 __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int H, int W, Kernel7<T> ka, T *__restrict__ bpad)
@@ -185,10 +215,29 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c0 = blockIdx.x * SRX_BT_W, r0 = blockIdx.y * SRX_BT_H;
     const T *src = hr + (size_t)blockIdx.z * H * W;
-    for (int idx = ty * 64 + tx; idx < (SRX_BT_H + 6) * (SRX_BT_W + 6); idx += 256) {
-        const int sr = idx / (SRX_BT_W + 6), sc = idx - sr * (SRX_BT_W + 6);
-        const int r = r0 - 3 + sr, c = c0 - 3 + sc;
-        tile[sr * SRX_BT_LDW + sc] = (r >= 0 && r < H && c >= 0 && c < W) ? src[(size_t)r * W + c] : (T)0;
+    {
+        // (32+6) x (64+6) source tile, zero outside the image: all loads first (clamped addresses), then the stores
+        constexpr int RPW = (SRX_BT_H + 6 + 3) / 4;  // 10 rows per wave
+        T v[RPW][2];
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int r = min(max(r0 - 3 + ty + 4 * j, 0), H - 1);
+            v[j][0] = src[(size_t)r * W + min(max(c0 - 3 + tx, 0), W - 1)];
+            v[j][1] = src[(size_t)r * W + min(max(c0 + 61 + (tx & 7), 0), W - 1)];  // columns 64..69 of the tile
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int sr = ty + 4 * j, r = r0 - 3 + sr;
+            if (sr < SRX_BT_H + 6) {
+                const bool rin = r >= 0 && r < H;
+                const int c = c0 - 3 + tx;
+                tile[sr * SRX_BT_LDW + tx] = (rin && c >= 0 && c < W) ? v[j][0] : (T)0;
+                if (tx < 6) {
+                    const int c2 = c0 + 61 + tx;
+                    tile[sr * SRX_BT_LDW + 64 + tx] = (rin && c2 >= 0 && c2 < W) ? v[j][1] : (T)0;
+                }
+            }
+        }
     }
     __syncthreads();
     T acc[8];
@@ -444,9 +493,7 @@ __global__ void __launch_bounds__(256)
     const int qa = max(0, f * j0 + omin_x - R), qb = min(Wp - 1, f * (j1 - 1) + omax_x + 3 + R);
     const int nr = pb - pa + 1, nc = qb - qa + 1;
     const T *src = bpad + (size_t)b * Hp * Wp + (size_t)pa * Wp + qa;
-    for (int rr = wave; rr < nr; rr += 4)
-        for (int cc = lane; cc < nc; cc += 64)
-            reg[rr * LD + cc] = src[(size_t)rr * Wp + cc];
+    load_region<T, FR, FR>(reg, LD, src, Wp, nr, nc, wave, lane);
     __syncthreads();
     // rows the 4x4 taps of this tile's LR pixels read
     tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid, f * i0 + omin_y - pa, f * (i1 - 1) + omax_y + 4 - pa);
@@ -576,6 +623,13 @@ __global__ void __launch_bounds__(256)
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
     const int nr = pb - pa, nc = qb - qa;
+    // this thread's TS*TS/256 hr pixels, fetched up front (clamped addresses): latency hides behind the tile work
+    T hv[TS / 32][8];
+#pragma unroll
+    for (int half = 0; half < TS / 32; half++)
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
     // ---- gather v: this thread owns region columns lane and lane+64; its wave walks rows wave, wave+4, ...
     const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
     const int q0 = qa + (c0ok ? lane : 0), q1 = qa + (c1ok ? lane + 64 : 0);
@@ -676,7 +730,7 @@ __global__ void __launch_bounds__(256)
                 const int r = r0 + half * 32 + wave * 8 + o;
                 if (r < H && c < W) {
                     const size_t i = base + (size_t)r * W + c;
-                    T v = hr_in[i] + step * a8[o] / n;
+                    T v = hv[half][o] + step * a8[o] / n;
                     hr_out[i] = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
                 }
             }

@@ -1,0 +1,522 @@
+// srx_mosaic.hpp -- the "mosaic" IBP path: when every frame's HR shift d_k = f*shift_k has the same
+// fractional part (per axis), the N per-frame resamplings of an iteration collapse into dense
+// operators plus ONE depth-to-space / space-to-depth index map (the PixelShuffle equivalence).
+//
+// Per axis write d_k = n_k + delta, n_k = floor(d_k), 0 <= delta < 1 common to all k.  With
+// c = P pad12(B hr) (SciPy's padded spline coefficients), the reference's forward model
+// (mono_cal_target/run_sr.py:161-165) is
+//     sim_k[i] = sum_a wf[a] c[f i + E - n_k + a],   E = 10 (delta > 0) or 11 (delta = 0), wf = bspline3(1 - delta)
+// i.e. every frame samples the SAME dense image  Y[P] = sum_a wf[a] c[P + a]  on its own lattice:
+//     sim_k[i] = Y[f i + E - n_k]                                    (space-to-depth of Y)
+// and its back-projection (:168-178) sums, over frames, 4-tap FIRs with the SAME weights wb = bspline3(delta)
+// of the zero-inserted, edge-padded residuals, so with
+//     G[p'] = sum_k up_k[clamp(p' + n_k - 13, 0, H-1)],  up_k[y] = err_k[y/f] on the lattice, else 0     (depth-to-space)
+//     v[p]  = sum_a wb[a] G[p + a],   corr = B' crop P v
+// Away from the first rows/columns a frame contributes to G[p'] iff u = p' + n_k - 13 is a lattice point
+// in [0, H-1], and then the Y sample it subtracts sits at Y[p' - D], D = 13 - E, for EVERY such frame:
+//     G[p'] = M[p'] - C[p'] * Y[p' - D],    M = sum of the contributing LR samples (a fixed mosaic of the
+//     input), C = how many frames contribute (a fixed count map).
+// Only the near band p' < 13 - min_k n_k (edge replication of LR row 0 into the pad) needs the explicit
+// per-frame sum; it is evaluated exactly there.  All of this is a re-association of the reference's own
+// sums -- no approximation beyond floating-point summation order.  With delta = 0 on both axes (the
+// reference's nominal +-0.5 px shifts at f = 2) the spline interpolation condition gives Y[P] = bpad[P+1]
+// and P(FIR(G))[p] = G[p+1]: no prefilter at all.
+//
+// One iteration:  k_blur_pad -> k_fwd_mosaic -> k_bwd_mosaic, each an O(1)-per-pixel dense pass.
+#pragma once
+#include "srx_fused.hpp"
+
+namespace srx {
+namespace mosaic {
+
+using fused::corr7_strip8;
+using fused::Kernel7;
+using fused::TileCfg;
+
+struct AxisPlan {
+    double delta;
+    int zero, E, D, PB;
+    int n[SRX_MAX_FRAMES];
+};
+
+struct AxisDev {  // kernel-argument part of a plan
+    int E, D;
+    int n[SRX_MAX_FRAMES];
+};
+
+template <typename T> struct MosaicArgs {
+    int Dy, Dx, PBy, PBx;
+    T wfy[4], wfx[4];  // forward FIR (after the prefilter)
+    T wby[4], wbx[4];  // backward FIR (before the prefilter)
+};
+
+struct MTap {
+    int i;    // LR index this frame contributes at this coordinate, or -1
+    int rho;  // Y row/column it subtracts there
+};
+
+// common fractional part detection (per axis); returns false if the frames do not share one
+static inline bool plan_axis(int N, const double *sh, int axis, int f, AxisPlan &pl)
+{
+    for (int k = 0; k < N; k++) {
+        const double d = sh[2 * k + axis] * f;
+        double n = std::floor(d), fr = d - n;
+        if (fr > 1.0 - 1e-12)
+            n += 1.0, fr = 0.0;
+        if (fr < 1e-12)
+            fr = 0.0;
+        if (k == 0)
+            pl.delta = fr;
+        else if (std::fabs(fr - pl.delta) > 1e-12)
+            return false;
+        pl.n[k] = (int)n;
+    }
+    pl.zero = pl.delta == 0.0;
+    pl.E = pl.zero ? 11 : 10;
+    pl.D = 13 - pl.E;
+    int nmin = pl.n[0];
+    for (int k = 1; k < N; k++)
+        nmin = std::min(nmin, pl.n[k]);
+    pl.PB = 13 - nmin;
+    return true;
+}
+
+static inline bool eligible(int N, int h, int w, const double *sh, int kh, int kw, int H, int W, int f)
+{
+    if (getenv("SRX_NO_MOSAIC") || !fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f) || f < 2)
+        return false;
+    AxisPlan a;
+    return plan_axis(N, sh, 0, f, a) && plan_axis(N, sh, 1, f, a) && H >= 32 && W >= 32;
+}
+
+// ---------------------------------------------------------------------------------------
+// tables: which LR sample of frame k lands on G coordinate p', and which Y sample it subtracts
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_build_mtaps(MTap *__restrict__ tab, int len, int n_img, int f, AxisDev ax)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+    if (p >= len)
+        return;
+    const int u = p + ax.n[k] - 13;
+    MTap t;
+    if (u < 0) {  // edge replication of up_k[0] into the pad
+        t.i = 0;
+        t.rho = ax.E - ax.n[k];
+    } else if (u <= n_img - 1 && u % f == 0) {
+        t.i = u / f;
+        t.rho = p - ax.D;
+    } else {
+        t.i = -1;
+        t.rho = 0;
+    }
+    tab[(size_t)k * len + p] = t;
+}
+
+// M = sum of contributing LR samples, C = their count, V = sum over far-field pixels of the within-pixel
+// scatter sum_k (l_k - mean)^2 (constant over the iterations; only non-zero when C > 1 somewhere)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_mosaic_build(const T *__restrict__ lr, int N, int h, int w, const MTap *__restrict__ tabY,
+                   const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, T *__restrict__ Mg,
+                   T *__restrict__ Cg, double *__restrict__ Vtot)
+{
+    __shared__ double part[4];
+    const int q = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    double var = 0.0;
+    if (p < Hg && q < Wg) {
+        double M = 0.0, S2 = 0.0;
+        int C = 0;
+        for (int k = 0; k < N; k++) {
+            const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
+            if (ty.i >= 0 && tx.i >= 0) {
+                const double l = (double)lr[(((size_t)b * N + k) * h + ty.i) * w + tx.i];
+                M += l;
+                S2 += l * l;
+                C++;
+            }
+        }
+        Mg[((size_t)b * Hg + p) * Wg + q] = (T)M;
+        if (b == 0)
+            Cg[(size_t)p * Wg + q] = (T)C;
+        if (C > 1 && p >= PBy && q >= PBx)
+            var = S2 - M * M / (double)C;
+    }
+    var = wave_sum(var);
+    if (threadIdx.x == 0)
+        part[threadIdx.y] = var;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const double s = part[0] + part[1] + part[2] + part[3];
+        if (s != 0.0)
+            atomicAdd(&Vtot[b], s);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors, const double *__restrict__ Vtot, int n_iter,
+                                                     int total, double scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total)
+        errors[i] = Vtot[i / n_iter] * scale;
+}
+
+// ---------------------------------------------------------------------------------------
+// line walkers on LDS: recursive prefilter fused with the 4-tap spline FIR
+// ---------------------------------------------------------------------------------------
+// c = P(x) in place, then line[P] = sum_a w[a] c[P + a] for P <= n - 4  (forward: FIR after the prefilter)
+template <typename T> __device__ __forceinline__ void line_iir_fir(T *line, int n, int stride, bool edge, const T w[4])
+{
+    const T z = pole<T>();
+    constexpr int K = Warmup<T>::n;
+    T prev = 0;
+    if (edge) {
+        T zi = 1, acc = 0;
+        const int kk = min(K, n);
+        for (int i = 0; i < kk; i++) {
+            acc += zi * line[i * stride];
+            zi *= z;
+        }
+        prev = (T)6 * acc;
+    }
+#pragma unroll 4
+    for (int i = 0; i < n; i++) {
+        prev = (T)6 * line[i * stride] + z * prev;
+        line[i * stride] = prev;
+    }
+    T next = prev * (z / (z - (T)1));
+    T a1 = next, a2 = 0, a3 = 0;  // c[i+1], c[i+2], c[i+3]
+#pragma unroll 4
+    for (int i = n - 2; i >= 0; i--) {
+        next = z * (next - line[i * stride]);
+        line[i * stride] = w[0] * next + w[1] * a1 + w[2] * a2 + w[3] * a3;  // valid Y for i <= n-4
+        a3 = a2;
+        a2 = a1;
+        a1 = next;
+    }
+}
+
+// v[i] = sum_a w[a] g[i + a], i < n_in - 3, then P(v) in place at line[0 .. n_in-4]  (backward: FIR before)
+template <typename T> __device__ __forceinline__ void line_fir_iir(T *line, int n_in, int stride, bool edge, const T w[4])
+{
+    const T z = pole<T>();
+    constexpr int K = Warmup<T>::n;
+    const int n = n_in - 3;
+    T prev = 0;
+    if (edge) {
+        T zi = 1, acc = 0;
+        const int kk = min(K, n);
+        T g0 = line[0], g1 = line[stride], g2 = line[2 * stride];
+        for (int i = 0; i < kk; i++) {
+            const T g3 = line[(i + 3) * stride];
+            acc += zi * (w[0] * g0 + w[1] * g1 + w[2] * g2 + w[3] * g3);
+            zi *= z;
+            g0 = g1, g1 = g2, g2 = g3;
+        }
+        prev = (T)6 * acc;
+    }
+    T g0 = line[0], g1 = line[stride], g2 = line[2 * stride];
+#pragma unroll 4
+    for (int i = 0; i < n; i++) {
+        const T g3 = line[(i + 3) * stride];
+        prev = (T)6 * (w[0] * g0 + w[1] * g1 + w[2] * g2 + w[3] * g3) + z * prev;
+        line[i * stride] = prev;
+        g0 = g1, g1 = g2, g2 = g3;
+    }
+    T next = prev * (z / (z - (T)1));
+    line[(n - 1) * stride] = next;
+#pragma unroll 4
+    for (int i = n - 2; i >= 0; i--) {
+        next = z * (next - line[i * stride]);
+        line[i * stride] = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// FWD: G = (depth-to-space of the residuals) = M - C * Y[. - D]   (+ exact near band), MSE trace
+//   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
+//   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
+// ---------------------------------------------------------------------------------------
+template <typename T, bool ZERO>
+__global__ void __launch_bounds__(256)
+    k_fwd_mosaic(const T *__restrict__ bpad, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
+                 int Wg, MosaicArgs<T> ma, const MTap *__restrict__ tabY, const MTap *__restrict__ tabX,
+                 const T *__restrict__ lr, int N, int h, int w, T *__restrict__ G, double *__restrict__ errors,
+                 int errors_stride, double scale)
+{
+    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
+    __shared__ T reg[ZERO ? 1 : FR * LD];
+    __shared__ double part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = blockIdx.y * TS, q0 = blockIdx.x * TS, b = blockIdx.z;
+    const T *src = bpad + (size_t)b * Hp * Wp;
+    // far-field operands of this thread's TS*TS/256 pixels, fetched up front (clamped addresses) so that their
+    // latency hides behind the tile's prefilter
+    constexpr int NPX = TS * TS / 256;
+    T Cv[NPX], Mv[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int idx = tid + 256 * j;
+        const size_t gi = (size_t)min(p0 + idx / TS, Hg - 1) * Wg + min(q0 + idx % TS, Wg - 1);
+        Cv[j] = Cg[gi];
+        Mv[j] = Mg[(size_t)b * Hg * Wg + gi];
+    }
+    int pa = 0, qa = 0;
+    if (!ZERO) {
+        pa = max(0, p0 - ma.Dy - R);
+        qa = max(0, q0 - ma.Dx - R);
+        const int pb = min(Hp, p0 - ma.Dy + TS + 3 + R), qb = min(Wp, q0 - ma.Dx + TS + 3 + R);
+        const int nr = pb - pa, nc = qb - qa;  // > 3 for every tile that holds a contributing pixel
+        if (nr > 3 && nc > 3) {
+            fused::load_region<T, FR, FR>(reg, LD, src + (size_t)pa * Wp + qa, Wp, nr, nc, wave, lane);
+            __syncthreads();
+            for (int c = tid; c < nc; c += 256)
+                line_iir_fir<T>(reg + c, nr, LD, pa == 0, ma.wfy);
+            __syncthreads();
+            // rows of Y this tile reads: [p0 - Dy, p0 - Dy + TS); near-band tiles also read rows E - n_k >= 0
+            const int r_lo = p0 < ma.PBy ? 0 : max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
+            for (int r = r_lo + tid; r < r_hi; r += 256)
+                line_iir_fir<T>(reg + r * LD, nc, 1, qa == 0, ma.wfx);
+        }
+        __syncthreads();
+    }
+    auto Y = [&](int P, int Q) -> T {
+        return ZERO ? src[(size_t)(P + 1) * Wp + Q + 1] : reg[(P - pa) * LD + (Q - qa)];
+    };
+    double sq = 0.0;
+    // ---- far field: one Y sample per pixel ----
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int idx = tid + 256 * j;
+        const int pg = p0 + idx / TS, qg = q0 + idx % TS;  // TS is a power of two
+        if (pg >= Hg || qg >= Wg || pg < ma.PBy || qg < ma.PBx)
+            continue;
+        const T C = Cv[j];
+        T g = 0;
+        if (C > (T)0) {
+            g = Mv[j] - C * Y(pg - ma.Dy, qg - ma.Dx);
+            sq += (double)g * (double)g / (double)C;
+        }
+        G[((size_t)b * Hg + pg) * Wg + qg] = g;
+    }
+    // ---- near band (first PBy rows / PBx columns of the plane): LR row/column 0 is edge-replicated into the
+    // pad, so a frame contributes at several coordinates and subtracts different Y samples -- the reference's
+    // sum, frame by frame.  The band's pixels of this tile are enumerated densely so that no lane idles.
+    const int nby = min(max(ma.PBy - p0, 0), TS), nbx = min(max(ma.PBx - q0, 0), TS);
+    const int n_near = nby * TS + (TS - nby) * nbx;
+    for (int idx = tid; idx < n_near; idx += 256) {
+        int pr, qc;
+        if (idx < nby * TS) {
+            pr = idx / TS, qc = idx % TS;
+        } else {
+            const int j = idx - nby * TS;
+            pr = nby + j / nbx, qc = j % nbx;
+        }
+        const int pg = p0 + pr, qg = q0 + qc;
+        if (pg >= Hg || qg >= Wg)
+            continue;
+        T g = 0;
+        // (loads are unconditional, from clamped indices, so that they can be issued back to back)
+#pragma unroll 4
+        for (int k = 0; k < N; k++) {
+            const MTap ty = tabY[(size_t)k * Hg + pg], tx = tabX[(size_t)k * Wg + qg];
+            const bool valid = ty.i >= 0 && tx.i >= 0;
+            const T l = lr[(((size_t)b * N + k) * h + max(ty.i, 0)) * w + max(tx.i, 0)];
+            const T y = Y(valid ? ty.rho : pa, valid ? tx.rho : qa);
+            const T e = valid ? l - y : (T)0;
+            g += e;
+            if (valid && ty.rho == pg - ma.Dy && tx.rho == qg - ma.Dx)  // the sample's own (unreplicated) position
+                sq += (double)e * (double)e;
+        }
+        G[((size_t)b * Hg + pg) * Wg + qg] = g;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0)
+        part[wave] = sq;
+    __syncthreads();
+    if (tid == 0 && errors) {
+        const double s = part[0] + part[1] + part[2] + part[3];
+        if (s != 0.0)
+            atomicAdd(&errors[(size_t)b * errors_stride], s * scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// BWD: hr = clip(hr + step * B'( crop P FIR_b G ) / n).  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
+//   ZERO: P FIR_b G [p] = G[p + 1] (interpolation condition) -> B' reads G directly.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool ZERO, bool SEP>
+__global__ void __launch_bounds__(256)
+    k_bwd_mosaic(const T *__restrict__ G, int Hg, int Wg, MosaicArgs<T> ma, int H, int W, Kernel7<T> kt, T step, T n,
+                 const T *__restrict__ hr_in, T *__restrict__ hr_out)
+{
+    constexpr int R = ZERO ? 0 : TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 3;  // odd
+    __shared__ T reg[(BR + 3) * LD];
+    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    const T *src = G + (size_t)b * Hg * Wg;
+    // padded rows of c' the 7x7 window of this tile reads: [r0+9, r0+TS+15); R more on each side for the recursion
+    const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
+    const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
+    const int nr = pb - pa, nc = qb - qa;
+    // this thread's TS*TS/256 hr pixels, fetched up front (clamped addresses): latency hides behind the tile work
+    T hv[TS / 32][8];
+#pragma unroll
+    for (int half = 0; half < TS / 32; half++)
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
+    if (ZERO) {
+        // c'[p, q] = G[p+1, q+1]
+        fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)(pa + 1) * Wg + qa + 1, Wg, nr, nc, wave, lane);
+        __syncthreads();
+    } else {
+        fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
+        __syncthreads();
+        for (int c = tid; c < nc + 3; c += 256)
+            line_fir_iir<T>(reg + c, nr + 3, LD, pa == 0, ma.wby);
+        __syncthreads();
+        const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
+        for (int r = r_lo + tid; r < r_hi; r += 256)
+            line_fir_iir<T>(reg + r * LD, nc + 3, 1, qa == 0, ma.wbx);
+        __syncthreads();
+    }
+    // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
+    if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
+        for (int rr = wave; rr < nr; rr += 4) {
+            const int p = pa + rr;
+            const bool rout = p < SRX_NPAD || p >= H + SRX_NPAD;
+            for (int cc = lane; cc < nc; cc += 64) {
+                const int q = qa + cc;
+                if (rout || q < SRX_NPAD || q >= W + SRX_NPAD)
+                    reg[rr * LD + cc] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
+    const int c = c0 + lane;
+    const size_t base = (size_t)b * H * W;
+#pragma unroll
+    for (int half = 0; half < TS / 32; half++) {
+        if (lane < TS) {
+            T a8[8];
+            corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const int r = r0 + half * 32 + wave * 8 + o;
+                if (r < H && c < W) {
+                    const size_t i = base + (size_t)r * W + c;
+                    T v = hv[half][o] + step * a8[o] / n;
+                    hr_out[i] = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
+{
+    const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
+    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
+           2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double));
+}
+
+template <typename T>
+static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
+               const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
+               size_t wsb, hipStream_t st)
+{
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
+    AxisPlan py, px;
+    if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
+        return SRX_E_UNSUPPORTED;
+    Arena ar(ws, wsb);
+    T *pad = ar.take<T>((size_t)B * Hp * Wp);
+    T *G = ar.take<T>((size_t)B * Hg * Wg), *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
+    MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
+    double *Vtot = ar.take<double>(B);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    AxisDev dy, dx;
+    dy.E = py.E, dy.D = py.D, dx.E = px.E, dx.D = px.D;
+    for (int q = 0; q < SRX_MAX_FRAMES; q++)
+        dy.n[q] = q < N ? py.n[q] : 0, dx.n[q] = q < N ? px.n[q] : 0;
+    MosaicArgs<T> ma;
+    ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB;
+    double wv[4];
+    fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wfy[i] = (T)wv[i];
+    fused::host_weights(px.zero ? 0.0 : 1.0 - px.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wfx[i] = (T)wv[i];
+    fused::host_weights(py.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wby[i] = (T)wv[i];
+    fused::host_weights(px.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wbx[i] = (T)wv[i];
+    Kernel7<T> kc, kt;
+    fused::make_kernel7<T>(k, kh, kw, false, kc);
+    fused::make_kernel7<T>(k, kh, kw, true, kt);
+    const bool sep = kc.separable && kt.separable, zero = py.zero && px.zero;
+    const size_t P = (size_t)B * H * W;
+    if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SRX_E_HIP;
+    if (n_iter == 0)
+        return SRX_OK;
+    // ---- once per call: index maps, LR mosaic, count map, constant part of the MSE trace ----
+    hipLaunchKernelGGL(k_build_mtaps, dim3(cdiv(Hg, 64), N), dim3(64), 0, st, tabY, Hg, H, f, dy);
+    SRX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_build_mtaps, dim3(cdiv(Wg, 64), N), dim3(64), 0, st, tabX, Wg, W, f, dx);
+    SRX_CHECK_LAUNCH();
+    if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
+        return SRX_E_HIP;
+    SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, N, h, w, tabY,
+               tabX, Hg, Wg, py.PB, px.PB, Mg, Cg, Vtot);
+    const double scale = 1.0 / ((double)h * (double)w) / (double)N;
+    if (errors) {
+        const int total = B * n_iter;
+        hipLaunchKernelGGL(k_init_errors, dim3(cdiv(total, 256)), dim3(256), 0, st, errors, Vtot, n_iter, total, scale);
+        SRX_CHECK_LAUNCH();
+    }
+    constexpr int TS = TileCfg<T>::T_HR;
+    const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
+    const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
+    for (int it = 0; it < n_iter; it++) {
+        const T *cur = it == 0 ? hr_init : hr;
+        double *eo = errors ? errors + it : nullptr;
+        if (sep)
+            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        else
+            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+        if (zero)
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
+                       tabX, lr, N, h, w, G, eo, n_iter, scale);
+        else
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
+                       tabX, lr, N, h, w, G, eo, n_iter, scale);
+#define SRX_BWDM(Z_, S_)                                                                                             \
+    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr)
+        if (zero) {
+            if (sep)
+                SRX_BWDM(true, true);
+            else
+                SRX_BWDM(true, false);
+        } else {
+            if (sep)
+                SRX_BWDM(false, true);
+            else
+                SRX_BWDM(false, false);
+        }
+#undef SRX_BWDM
+    }
+    return SRX_OK;
+}
+
+}  // namespace mosaic
+}  // namespace srx

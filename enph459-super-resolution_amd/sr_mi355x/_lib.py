@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "libsrx.so")
 _lib = None
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
-FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED = 0, 1, 2
+FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME = 0, 1, 2, 4
 
 _c = ctypes
 _P, _I, _D, _Z, _U = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED  # noqa: F401  (re-exported)
+from ._lib import FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME  # noqa: F401  (re-exported)
 
 _PRECISION = os.environ.get("SRX_PRECISION", "f32")
 _TORCH_DT = {"f32": torch.float32, "f64": torch.float64}

@@ -54,11 +54,14 @@ typedef enum {
 /* srx_ibp / srx_saa `flags` */
 #define SRX_FLAG_AUTO 0u     /* fused tile kernels when eligible, composed primitives otherwise */
 #define SRX_FLAG_COMPOSED 1u /* force the literal per-frame composition of the primitives */
-#define SRX_FLAG_FUSED 2u    /* require the fused path; SRX_E_UNSUPPORTED if not eligible */
+#define SRX_FLAG_FUSED 2u    /* require a fused path; SRX_E_UNSUPPORTED if not eligible */
+#define SRX_FLAG_PER_FRAME 4u /* fused, but never the "mosaic" (common-fraction, depth-to-space) formulation */
 
 int srx_version(void);
 const char *srx_strerror(int status);
-/* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took ("fused", "composed"). */
+/* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
+ * "mosaic" (all shifts share one sub-pixel fraction: dense depth-to-space formulation), "fused"
+ * (per-frame tile kernels), "composed" (primitives, frame by frame). */
 const char *srx_last_path(void);
 
 /* ---- measurement hook (no reference counterpart; used by bench.py's roofline leg) ----

@@ -218,21 +218,30 @@ def test_large_image_chunked_prefilter(prec):
     O.set_threads(1)
 
 
-@pytest.mark.parametrize("cfg", ["f2_meas", "f2_nom5", "f4_ph16", "f3_k5"])
+FUSED_CFGS = {
+    # name: (factor, shifts (LR px), psf, (h, w), expected path)
+    "f2_meas": (2, synth.MEASURED_4, "asym", (150, 277), "fused"),          # distinct sub-pixel fractions: per-frame tiles
+    "f3_k5": (3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], "asym5", (60, 75), "fused"),
+    "f2_nom5": (2, synth.NOMINAL_5, "gauss", (131, 200), "mosaic"),         # integer HR shifts: pure depth-to-space
+    "f4_nom4": (4, synth.NOMINAL_4, "asym", (70, 90), "mosaic"),
+    "f4_ph16": (4, synth.phase_shifts(4), "gauss", (70, 90), "mosaic"),     # the bench workload: all fractions 0.5
+    "f3_ph9": (3, synth.phase_shifts(3), "asym", (50, 66), "mosaic"),       # fractions 0 (3 phases centred on 0)
+    "f2_mixed": (2, [(0.5, 0.25), (-0.5, -0.25), (0.0, 0.75)], "asym", (90, 120), "mosaic"),  # y integer, x fraction 0.5
+    "f2_multi": (2, [(0.25, 0.25), (1.25, 0.25), (0.25, -0.75), (-0.75, 1.25)], "gauss", (90, 120), "mosaic"),  # C = 4 on one phase
+    "f4_frac": (4, [(0.05, 0.3), (0.3, 0.05), (-0.2, -0.45), (0.55, -0.2), (-0.45, 0.55)], "asym", (40, 50), "mosaic"),  # fractions 0.2
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(FUSED_CFGS))
 def test_fused_path_vs_oracle(prec, cfg):
-    """Fused tile path on an image spanning several tiles/chunks, against the oracle (literal restatement)."""
+    """Fused paths ("mosaic" when all shifts share one sub-pixel fraction, per-frame "fused" tiles otherwise) on
+    images spanning several tiles, against the oracle (the literal restatement of the reference's loop)."""
     from oracle import sr_oracle as O
     O.set_threads(8)
     try:
-        if cfg == "f2_meas":
-            f, shifts, psf, (h, w) = 2, synth.MEASURED_4, synth.asymmetric_psf(), (150, 277)
-        elif cfg == "f2_nom5":
-            f, shifts, psf, (h, w) = 2, synth.NOMINAL_5, synth.gaussian_psf(), (131, 200)
-        elif cfg == "f4_ph16":
-            f, shifts, psf, (h, w) = 4, synth.phase_shifts(4), synth.gaussian_psf(), (70, 90)
-        else:
-            f, shifts, psf, (h, w) = 3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], synth.asymmetric_psf()[1:6, 1:6], (60, 75)
-            psf = psf / psf.sum()
+        f, shifts, psf_name, (h, w), want = FUSED_CFGS[cfg]
+        psf = {"asym": synth.asymmetric_psf(), "gauss": synth.gaussian_psf(),
+               "asym5": synth.asymmetric_psf()[1:6, 1:6] / synth.asymmetric_psf()[1:6, 1:6].sum()}[psf_name]
         truth = synth.truth_image(h * f, w * f, seed=77)
         lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=78)
         saa_o = O.shift_and_add(list(lr), shifts, f)
@@ -243,10 +252,14 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "fused"
     close(saa, saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
-    assert S.last_path() == "fused"
+    assert S.last_path() == want
     close(hr, hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
-    # and the composed (literal) HIP path agrees with the fused one
+    # the composed (literal) and the per-frame fused HIP paths agree with it
     hr_c, errs_c = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_COMPOSED)
     assert S.last_path() == "composed"
     close(hr_c[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
+    hr_p, errs_p = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_PER_FRAME)
+    assert S.last_path() == "fused"
+    close(hr_p[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
+    np.testing.assert_allclose(errs_p[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
