@@ -207,8 +207,41 @@ __device__ __forceinline__ void load_region(T *__restrict__ reg, int ld, const T
     }
 }
 
+// Same, but the source is an UNPADDED image plane [H, W] read as its 12-px edge-replicated extension: region cell
+// (rr, cc) is padded coordinate (pa + rr, qa + cc) = image pixel (clamp(pa+rr-12), clamp(qa+cc-12)).  SciPy's
+// np.pad(mode='edge') is thus never materialised on the iteration path.
+template <typename T, int MAXR, int MAXC>
+__device__ __forceinline__ void load_region_pad(T *__restrict__ reg, int ld, const T *__restrict__ img, int H, int W,
+                                                int pa, int qa, int nr, int nc, int wave, int lane)
+{
+    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64, BATCH = 8;
+    int col[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; cc++)
+        col[cc] = min(max(qa + min(lane + 64 * cc, nc - 1) - SRX_NPAD, 0), W - 1);
+#pragma unroll
+    for (int j0 = 0; j0 < RPW; j0 += BATCH) {
+        T v[BATCH][CPL];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int row = min(max(pa + min(wave + 4 * (j0 + j), nr - 1) - SRX_NPAD, 0), H - 1);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                v[j][cc] = img[(size_t)row * W + col[cc]];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int rr = wave + 4 * (j0 + j);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                if (rr < nr && lane + 64 * cc < nc)
+                    reg[rr * ld + lane + 64 * cc] = v[j][cc];
+        }
+    }
+}
+
 // K_A: bpad = pad12_edge(B hr).  grid (ceil(W/64), ceil(H/32), B), block (64, 4).
-template <typename T, bool SEP>
+template <typename T, bool SEP, bool PAD = true>
 __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int H, int W, Kernel7<T> ka, T *__restrict__ bpad)
 {
     __shared__ T tile[(SRX_BT_H + 6) * SRX_BT_LDW];
@@ -242,11 +275,21 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     __syncthreads();
     T acc[8];
     corr7_strip8<T, SRX_BT_LDW, SEP>(tile, tx, ty, ka, acc);
-    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    T *dst = bpad + (size_t)blockIdx.z * Hp * Wp;
     const int c = c0 + tx;
     if (c >= W)
         return;
+    if (!PAD) {  // plain [H, W] plane; consumers read it through load_region_pad
+        T *out = bpad + (size_t)blockIdx.z * H * W;
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int r = r0 + ty * 8 + o;
+            if (r < H)
+                out[(size_t)r * W + c] = acc[o];
+        }
+        return;
+    }
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    T *dst = bpad + (size_t)blockIdx.z * Hp * Wp;
     const int clo = c == 0 ? 0 : c + SRX_NPAD, chi = c == W - 1 ? Wp - 1 : c + SRX_NPAD;
 #pragma unroll
     for (int o = 0; o < 8; o++) {
@@ -430,48 +473,120 @@ template <typename T> struct TileCfg;
 template <> struct TileCfg<float> { static constexpr int R = 12, T_HR = 64; };
 template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
 
-// One line of the recursive prefilter on LDS (in place).  Measured: the tile kernels are bound by
-// instruction issue, not by this chain's latency (other waves fill the gaps), so the loop is kept
-// minimal -- an explicitly software-pipelined variant with clamped look-ahead reads was 10-15 % slower.
-template <typename T> __device__ __forceinline__ void line_iir(T *line, int n, int stride, bool edge)
+// One line of the recursive cubic-spline prefilter on LDS, optionally fused with the 4-tap spline FIR:
+//   MODE 0: line <- P(line)                                      (n = n_in outputs)
+//   MODE 1: line[0..n) <- P(v), v[i] = sum_a w[a] line[i+a]       (FIR before; n = n_in - 3 outputs)
+//   MODE 2: line[i] <- sum_a w[a] c[i+a], c = P(line), i <= n-4   (FIR after)
+// S = element stride, a compile-time constant: with a run-time stride hipcc must assume that the store of
+// step i aliases the load of step i+1 and serialises one LDS round trip (~150 cycles) per step.  Here 8
+// samples are read, run through the serial recursion in registers and written back per trip.
+template <typename T, int S, int MODE>
+__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w)
 {
-    const T z = pole<T>();
-    constexpr int K = Warmup<T>::n;
+    constexpr int U = 8, K = Warmup<T>::n;
+    const T z = pole<T>(), zfin = z / (z - (T)1);
+    const int n = MODE == 1 ? n_in - 3 : n_in;
+    const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
     T prev = 0;
-    if (edge) {  // exact 'reflect' end: c+[0] = 6 x[0] + z * sum_i z^i 6 x[i]
+    if (edge) {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
         T zi = 1, acc = 0;
         const int kk = min(K, n);
+        T g0 = line[0], g1 = MODE == 1 ? line[S] : (T)0, g2 = MODE == 1 ? line[2 * S] : (T)0;
         for (int i = 0; i < kk; i++) {
-            acc += zi * line[i * stride];
+            T v;
+            if (MODE == 1) {
+                const T g3 = line[(i + 3) * S];
+                v = w0 * g0 + w1 * g1 + w2 * g2 + w3 * g3;
+                g0 = g1, g1 = g2, g2 = g3;
+            } else {
+                v = line[i * S];
+            }
+            acc += zi * v;
             zi *= z;
         }
         prev = (T)6 * acc;
     }
-#pragma unroll 4
-    for (int i = 0; i < n; i++) {
-        prev = (T)6 * line[i * stride] + z * prev;
-        line[i * stride] = prev;
+    // ---- causal ----
+    T g0 = 0, g1 = 0, g2 = 0;
+    if (MODE == 1)
+        g0 = line[0], g1 = line[S], g2 = line[2 * S];
+    int base = 0;
+    for (; base + U <= n; base += U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = line[(base + u + (MODE == 1 ? 3 : 0)) * S];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            T v = x[u];
+            if (MODE == 1) {
+                v = w0 * g0 + w1 * g1 + w2 * g2 + w3 * x[u];
+                g0 = g1, g1 = g2, g2 = x[u];
+            }
+            prev = (T)6 * v + z * prev;
+            x[u] = prev;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            line[(base + u) * S] = x[u];
     }
-    T next = prev * (z / (z - (T)1));
-    line[(n - 1) * stride] = next;
-#pragma unroll 4
-    for (int i = n - 2; i >= 0; i--) {
-        next = z * (next - line[i * stride]);
-        line[i * stride] = next;
+    for (; base < n; base++) {
+        T v = line[(base + (MODE == 1 ? 3 : 0)) * S];
+        if (MODE == 1) {
+            const T g3 = v;
+            v = w0 * g0 + w1 * g1 + w2 * g2 + w3 * g3;
+            g0 = g1, g1 = g2, g2 = g3;
+        }
+        prev = (T)6 * v + z * prev;
+        line[base * S] = prev;
+    }
+    // ---- anticausal ----
+    T next = prev * zfin;
+    T a1 = next, a2 = 0, a3 = 0;  // c[i+1], c[i+2], c[i+3]
+    if (MODE != 2)
+        line[(n - 1) * S] = next;
+    int i = n - 2;
+    for (; i - (U - 1) >= 0; i -= U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = line[(i - u) * S];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            next = z * (next - x[u]);
+            if (MODE == 2) {
+                x[u] = w0 * next + w1 * a1 + w2 * a2 + w3 * a3;  // a valid FIR output for i-u <= n-4
+                a3 = a2, a2 = a1, a1 = next;
+            } else {
+                x[u] = next;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            line[(i - u) * S] = x[u];
+    }
+    for (; i >= 0; i--) {
+        next = z * (next - line[i * S]);
+        if (MODE == 2) {
+            line[i * S] = w0 * next + w1 * a1 + w2 * a2 + w3 * a3;
+            a3 = a2, a2 = a1, a1 = next;
+        } else {
+            line[i * S] = next;
+        }
     }
 }
 
-// in-place 2-D prefilter of an LDS region [nr x nc], row stride ld (odd: conflict-free row walks).
+// in-place 2-D prefilter of an LDS region [nr x nc], row stride LD (odd: conflict-free row walks).
 // Axis 0 runs over all nc columns; axis 1 only over rows [r_lo, r_hi) (the rows a consumer reads).
-template <typename T, int NT>
-__device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, int ld, bool top_edge, bool left_edge, int tid,
-                                           int r_lo, int r_hi)
+template <typename T, int NT, int LD>
+__device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, bool top_edge, bool left_edge, int tid, int r_lo,
+                                           int r_hi)
 {
     for (int c = tid; c < nc; c += NT)
-        line_iir<T>(reg + c, nr, ld, top_edge);
+        walk_line<T, LD, 0>(reg + c, nr, top_edge, nullptr);
     __syncthreads();
     for (int r = r_lo + tid; r < r_hi; r += NT)
-        line_iir<T>(reg + r * ld, nc, 1, left_edge);
+        walk_line<T, 1, 0>(reg + r * LD, nc, left_edge, nullptr);
     __syncthreads();
 }
 
@@ -479,7 +594,7 @@ __device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, int ld, bool 
 // One block per LR tile th x tw (f*th <= T_HR).  grid (ceil(w/tw), ceil(h/th), B), block 256.
 template <typename T>
 __global__ void __launch_bounds__(256)
-    k_fwd_tile(const T *__restrict__ bpad, int Hp, int Wp, const T *__restrict__ lr, int h, int w, int f,
+    k_fwd_tile(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ lr, int h, int w, int f,
                FrameSet<T> fs, int omin_y, int omax_y, int omin_x, int omax_x, int th, int tw, T *__restrict__ err,
                double *__restrict__ errors, int errors_stride, double scale)
 {
@@ -492,11 +607,11 @@ __global__ void __launch_bounds__(256)
     const int pa = max(0, f * i0 + omin_y - R), pb = min(Hp - 1, f * (i1 - 1) + omax_y + 3 + R);
     const int qa = max(0, f * j0 + omin_x - R), qb = min(Wp - 1, f * (j1 - 1) + omax_x + 3 + R);
     const int nr = pb - pa + 1, nc = qb - qa + 1;
-    const T *src = bpad + (size_t)b * Hp * Wp + (size_t)pa * Wp + qa;
-    load_region<T, FR, FR>(reg, LD, src, Wp, nr, nc, wave, lane);
+    const int H = Hp - 2 * SRX_NPAD, W = Wp - 2 * SRX_NPAD;
+    load_region_pad<T, FR, FR>(reg, LD, bimg + (size_t)b * H * W, H, W, pa, qa, nr, nc, wave, lane);
     __syncthreads();
     // rows the 4x4 taps of this tile's LR pixels read
-    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid, f * i0 + omin_y - pa, f * (i1 - 1) + omax_y + 4 - pa);
+    tile_iir2d<T, 256, LD>(reg, nr, nc, pa == 0, qa == 0, tid, f * i0 + omin_y - pa, f * (i1 - 1) + omax_y + 4 - pa);
     const int N = fs.n;
     double sq = 0.0;
     for (int idx = tid; idx < th * tw; idx += 256) {
@@ -702,7 +817,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     // rows the 7x7 window of this tile reads: image rows [r0-3, r0+TS+3)
-    tile_iir2d<T, 256>(reg, nr, nc, LD, pa == 0, qa == 0, tid, r0 + 9 - pa, min(r0 + TS + 15, Hp) - pa);
+    tile_iir2d<T, 256, LD>(reg, nr, nc, pa == 0, qa == 0, tid, r0 + 9 - pa, min(r0 + TS + 15, Hp) - pa);
     // ---- B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
     if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
         for (int rr = wave; rr < nr; rr += 4) {
@@ -786,9 +901,9 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
         if (sep)
-            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, true>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
-            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+            SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
                    omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
 if (sep)

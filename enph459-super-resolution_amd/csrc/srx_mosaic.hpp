@@ -161,94 +161,24 @@ __global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors
 }
 
 // ---------------------------------------------------------------------------------------
-// line walkers on LDS: recursive prefilter fused with the 4-tap spline FIR
-// ---------------------------------------------------------------------------------------
-// c = P(x) in place, then line[P] = sum_a w[a] c[P + a] for P <= n - 4  (forward: FIR after the prefilter)
-template <typename T> __device__ __forceinline__ void line_iir_fir(T *line, int n, int stride, bool edge, const T w[4])
-{
-    const T z = pole<T>();
-    constexpr int K = Warmup<T>::n;
-    T prev = 0;
-    if (edge) {
-        T zi = 1, acc = 0;
-        const int kk = min(K, n);
-        for (int i = 0; i < kk; i++) {
-            acc += zi * line[i * stride];
-            zi *= z;
-        }
-        prev = (T)6 * acc;
-    }
-#pragma unroll 4
-    for (int i = 0; i < n; i++) {
-        prev = (T)6 * line[i * stride] + z * prev;
-        line[i * stride] = prev;
-    }
-    T next = prev * (z / (z - (T)1));
-    T a1 = next, a2 = 0, a3 = 0;  // c[i+1], c[i+2], c[i+3]
-#pragma unroll 4
-    for (int i = n - 2; i >= 0; i--) {
-        next = z * (next - line[i * stride]);
-        line[i * stride] = w[0] * next + w[1] * a1 + w[2] * a2 + w[3] * a3;  // valid Y for i <= n-4
-        a3 = a2;
-        a2 = a1;
-        a1 = next;
-    }
-}
-
-// v[i] = sum_a w[a] g[i + a], i < n_in - 3, then P(v) in place at line[0 .. n_in-4]  (backward: FIR before)
-template <typename T> __device__ __forceinline__ void line_fir_iir(T *line, int n_in, int stride, bool edge, const T w[4])
-{
-    const T z = pole<T>();
-    constexpr int K = Warmup<T>::n;
-    const int n = n_in - 3;
-    T prev = 0;
-    if (edge) {
-        T zi = 1, acc = 0;
-        const int kk = min(K, n);
-        T g0 = line[0], g1 = line[stride], g2 = line[2 * stride];
-        for (int i = 0; i < kk; i++) {
-            const T g3 = line[(i + 3) * stride];
-            acc += zi * (w[0] * g0 + w[1] * g1 + w[2] * g2 + w[3] * g3);
-            zi *= z;
-            g0 = g1, g1 = g2, g2 = g3;
-        }
-        prev = (T)6 * acc;
-    }
-    T g0 = line[0], g1 = line[stride], g2 = line[2 * stride];
-#pragma unroll 4
-    for (int i = 0; i < n; i++) {
-        const T g3 = line[(i + 3) * stride];
-        prev = (T)6 * (w[0] * g0 + w[1] * g1 + w[2] * g2 + w[3] * g3) + z * prev;
-        line[i * stride] = prev;
-        g0 = g1, g1 = g2, g2 = g3;
-    }
-    T next = prev * (z / (z - (T)1));
-    line[(n - 1) * stride] = next;
-#pragma unroll 4
-    for (int i = n - 2; i >= 0; i--) {
-        next = z * (next - line[i * stride]);
-        line[i * stride] = next;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // FWD: G = (depth-to-space of the residuals) = M - C * Y[. - D]   (+ exact near band), MSE trace
 //   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
 //   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
 // ---------------------------------------------------------------------------------------
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
-    k_fwd_mosaic(const T *__restrict__ bpad, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
+    k_fwd_mosaic(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
                  int Wg, MosaicArgs<T> ma, const MTap *__restrict__ tabY, const MTap *__restrict__ tabX,
                  const T *__restrict__ lr, int N, int h, int w, T *__restrict__ G, double *__restrict__ errors,
-                 int errors_stride, double scale)
+                 int errors_stride, double scale, int dbg)
 {
     constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
     __shared__ T reg[ZERO ? 1 : FR * LD];
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p0 = blockIdx.y * TS, q0 = blockIdx.x * TS, b = blockIdx.z;
-    const T *src = bpad + (size_t)b * Hp * Wp;
+    const int H = Hp - 2 * SRX_NPAD, W = Wp - 2 * SRX_NPAD;
+    const T *src = bimg + (size_t)b * H * W;  // plain blurred plane; its 12-px edge extension is applied on the fly
     // far-field operands of this thread's TS*TS/256 pixels, fetched up front (clamped addresses) so that their
     // latency hides behind the tile's prefilter
     constexpr int NPX = TS * TS / 256;
@@ -267,20 +197,23 @@ __global__ void __launch_bounds__(256)
         const int pb = min(Hp, p0 - ma.Dy + TS + 3 + R), qb = min(Wp, q0 - ma.Dx + TS + 3 + R);
         const int nr = pb - pa, nc = qb - qa;  // > 3 for every tile that holds a contributing pixel
         if (nr > 3 && nc > 3) {
-            fused::load_region<T, FR, FR>(reg, LD, src + (size_t)pa * Wp + qa, Wp, nr, nc, wave, lane);
+            fused::load_region_pad<T, FR, FR>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
+            if (!(dbg & 1))
             for (int c = tid; c < nc; c += 256)
-                line_iir_fir<T>(reg + c, nr, LD, pa == 0, ma.wfy);
+                fused::walk_line<T, LD, 2>(reg + c, nr, pa == 0, ma.wfy);
             __syncthreads();
             // rows of Y this tile reads: [p0 - Dy, p0 - Dy + TS); near-band tiles also read rows E - n_k >= 0
             const int r_lo = p0 < ma.PBy ? 0 : max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
+            if (!(dbg & 2))
             for (int r = r_lo + tid; r < r_hi; r += 256)
-                line_iir_fir<T>(reg + r * LD, nc, 1, qa == 0, ma.wfx);
+                fused::walk_line<T, 1, 2>(reg + r * LD, nc, qa == 0, ma.wfx);
         }
         __syncthreads();
     }
     auto Y = [&](int P, int Q) -> T {
-        return ZERO ? src[(size_t)(P + 1) * Wp + Q + 1] : reg[(P - pa) * LD + (Q - qa)];
+        return ZERO ? src[(size_t)min(max(P + 1 - SRX_NPAD, 0), H - 1) * W + min(max(Q + 1 - SRX_NPAD, 0), W - 1)]
+                    : reg[(P - pa) * LD + (Q - qa)];
     };
     double sq = 0.0;
     // ---- far field: one Y sample per pixel ----
@@ -288,7 +221,7 @@ __global__ void __launch_bounds__(256)
     for (int j = 0; j < NPX; j++) {
         const int idx = tid + 256 * j;
         const int pg = p0 + idx / TS, qg = q0 + idx % TS;  // TS is a power of two
-        if (pg >= Hg || qg >= Wg || pg < ma.PBy || qg < ma.PBx)
+        if (pg >= Hg || qg >= Wg || pg < ma.PBy || qg < ma.PBx || (dbg & 8))
             continue;
         const T C = Cv[j];
         T g = 0;
@@ -302,7 +235,7 @@ __global__ void __launch_bounds__(256)
     // pad, so a frame contributes at several coordinates and subtracts different Y samples -- the reference's
     // sum, frame by frame.  The band's pixels of this tile are enumerated densely so that no lane idles.
     const int nby = min(max(ma.PBy - p0, 0), TS), nbx = min(max(ma.PBx - q0, 0), TS);
-    const int n_near = nby * TS + (TS - nby) * nbx;
+    const int n_near = (dbg & 4) ? 0 : nby * TS + (TS - nby) * nbx;
     for (int idx = tid; idx < n_near; idx += 256) {
         int pr, qc;
         if (idx < nby * TS) {
@@ -374,11 +307,11 @@ __global__ void __launch_bounds__(256)
         fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
         __syncthreads();
         for (int c = tid; c < nc + 3; c += 256)
-            line_fir_iir<T>(reg + c, nr + 3, LD, pa == 0, ma.wby);
+            fused::walk_line<T, LD, 1>(reg + c, nr + 3, pa == 0, ma.wby);
         __syncthreads();
         const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
         for (int r = r_lo + tid; r < r_hi; r += 256)
-            line_fir_iir<T>(reg + r * LD, nc + 3, 1, qa == 0, ma.wbx);
+            fused::walk_line<T, 1, 1>(reg + r * LD, nc + 3, qa == 0, ma.wbx);
         __syncthreads();
     }
     // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
@@ -485,21 +418,22 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         SRX_CHECK_LAUNCH();
     }
     constexpr int TS = TileCfg<T>::T_HR;
+    const int dbg = getenv("SRX_DBG") ? atoi(getenv("SRX_DBG")) : 0;  // timing ablations only (results are wrong)
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
         double *eo = errors ? errors + it : nullptr;
         if (sep)
-            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
-            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
+            SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         if (zero)
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
-                       tabX, lr, N, h, w, G, eo, n_iter, scale);
+                       tabX, lr, N, h, w, G, eo, n_iter, scale, dbg);
         else
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
-                       tabX, lr, N, h, w, G, eo, n_iter, scale);
+                       tabX, lr, N, h, w, G, eo, n_iter, scale, dbg);
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr)
         if (zero) {
