@@ -45,7 +45,8 @@ struct AxisDev {  // kernel-argument part of a plan
 };
 
 template <typename T> struct MosaicArgs {
-    int Dy, Dx, PBy, PBx;
+    int Dy, Dx, PBy, PBx;  // G coordinates p' < PB form the near band (edge-replicated LR row/column 0)
+    int YBy, YBx;          // Y rows < YBy / columns < YBx are what near-band pixels subtract
     T wfy[4], wfx[4];  // forward FIR (after the prefilter)
     T wby[4], wbx[4];  // backward FIR (before the prefilter)
 };
@@ -161,6 +162,87 @@ __global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors
 }
 
 // ---------------------------------------------------------------------------------------
+// near band: per pixel, the compact list of frames that contribute there (built once per call)
+// ---------------------------------------------------------------------------------------
+struct NEnt {
+    int off;   // offset of the LR sample inside one item's [N, h, w] stack
+    int yoff;  // offset of the Y sample it subtracts inside one item's Y source plane
+    int unc;   // 1 if this is the sample's own (unreplicated) position: counts for the MSE trace
+};
+
+__device__ __forceinline__ void near_px(int idx, int Wg, int PBy, int PBx, int &p, int &q)
+{
+    if (idx < PBy * Wg) {
+        p = idx / Wg, q = idx - p * Wg;
+    } else {
+        const int j = idx - PBy * Wg;
+        p = PBy + j / PBx, q = j % PBx;
+    }
+}
+
+// ZERO: the Y source is the plain blurred plane [H, W] (Y[P,Q] = b[clamp(P-11), clamp(Q-11)]); else the Yb plane [Hp, Wp]
+__global__ void __launch_bounds__(256)
+    k_build_near(const MTap *__restrict__ tabY, const MTap *__restrict__ tabX, int N, int h, int w, int Hg, int Wg, int PBy,
+                 int PBx, int Dy, int Dx, int zero, int H, int W, int NB, int *__restrict__ ncnt, NEnt *__restrict__ nent)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NB)
+        return;
+    int p, q;
+    near_px(idx, Wg, PBy, PBx, p, q);
+    int cnt = 0;
+    for (int k = 0; k < N; k++) {
+        const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
+        if (ty.i >= 0 && tx.i >= 0) {
+            NEnt e;
+            e.off = (k * h + ty.i) * w + tx.i;
+            e.yoff = zero ? min(max(ty.rho + 1 - SRX_NPAD, 0), H - 1) * W + min(max(tx.rho + 1 - SRX_NPAD, 0), W - 1)
+                          : ty.rho * (W + 2 * SRX_NPAD) + tx.rho;
+            e.unc = (ty.rho == p - Dy && tx.rho == q - Dx) ? 1 : 0;
+            nent[(size_t)idx * N + cnt++] = e;
+        }
+    }
+    ncnt[idx] = cnt;
+}
+
+// G on the near band: the reference's sum, frame by frame, over the frames that land on each pixel
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_fwd_near(const T *__restrict__ lr, size_t lr_item, const T *__restrict__ ysrc, size_t y_item, int N, int Hg, int Wg,
+               int PBy, int PBx, int NB, const int *__restrict__ ncnt, const NEnt *__restrict__ nent, T *__restrict__ G,
+               double *__restrict__ errors, int errors_stride, double scale)
+{
+    __shared__ double part[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    double sq = 0.0;
+    if (idx < NB) {
+        int p, q;
+        near_px(idx, Wg, PBy, PBx, p, q);
+        const int cnt = ncnt[idx];
+        const NEnt *ent = nent + (size_t)idx * N;
+        const T *l0 = lr + (size_t)b * lr_item, *y0 = ysrc + (size_t)b * y_item;
+        T g = 0;
+        for (int e = 0; e < cnt; e++) {
+            const NEnt en = ent[e];
+            const T d = l0[en.off] - y0[en.yoff];
+            g += d;
+            if (en.unc)
+                sq += (double)d * (double)d;
+        }
+        G[((size_t)b * Hg + p) * Wg + q] = g;
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && errors) {
+        const double s = part[0] + part[1] + part[2] + part[3];
+        if (s != 0.0)
+            atomicAdd(&errors[(size_t)b * errors_stride], s * scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FWD: G = (depth-to-space of the residuals) = M - C * Y[. - D]   (+ exact near band), MSE trace
 //   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
 //   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
@@ -168,8 +250,7 @@ __global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
     k_fwd_mosaic(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
-                 int Wg, MosaicArgs<T> ma, const MTap *__restrict__ tabY, const MTap *__restrict__ tabX,
-                 const T *__restrict__ lr, int N, int h, int w, T *__restrict__ G, double *__restrict__ errors,
+                 int Wg, MosaicArgs<T> ma, T *__restrict__ Yb, T *__restrict__ G, double *__restrict__ errors,
                  int errors_stride, double scale, int dbg)
 {
     constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
@@ -203,8 +284,8 @@ __global__ void __launch_bounds__(256)
             for (int c = tid; c < nc; c += 256)
                 fused::walk_line<T, LD, 2>(reg + c, nr, pa == 0, ma.wfy);
             __syncthreads();
-            // rows of Y this tile reads: [p0 - Dy, p0 - Dy + TS); near-band tiles also read rows E - n_k >= 0
-            const int r_lo = p0 < ma.PBy ? 0 : max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
+            // rows of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS)
+            const int r_lo = max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
             if (!(dbg & 2))
             for (int r = r_lo + tid; r < r_hi; r += 256)
                 fused::walk_line<T, 1, 2>(reg + r * LD, nc, qa == 0, ma.wfx);
@@ -216,49 +297,26 @@ __global__ void __launch_bounds__(256)
                     : reg[(P - pa) * LD + (Q - qa)];
     };
     double sq = 0.0;
-    // ---- far field: one Y sample per pixel ----
+    // ---- far field: one Y sample per pixel.  Pixels of the near band (first PBy rows / PBx columns, where LR
+    // row/column 0 is edge-replicated into the pad and frames subtract different Y samples) are left to
+    // k_fwd_near; this kernel only publishes the Y rows/columns they read (Yb).
 #pragma unroll
     for (int j = 0; j < NPX; j++) {
         const int idx = tid + 256 * j;
         const int pg = p0 + idx / TS, qg = q0 + idx % TS;  // TS is a power of two
-        if (pg >= Hg || qg >= Wg || pg < ma.PBy || qg < ma.PBx || (dbg & 8))
+        if (pg >= Hg || qg >= Wg || (dbg & 8))
+            continue;
+        const int P = pg - ma.Dy, Q = qg - ma.Dx;
+        const bool far = pg >= ma.PBy && qg >= ma.PBx;
+        if (!ZERO && P >= 0 && Q >= 0 && P <= Hp - 4 && Q <= Wp - 4 && (P < ma.YBy || Q < ma.YBx))
+            Yb[((size_t)b * Hp + P) * Wp + Q] = Y(P, Q);
+        if (!far)
             continue;
         const T C = Cv[j];
         T g = 0;
         if (C > (T)0) {
-            g = Mv[j] - C * Y(pg - ma.Dy, qg - ma.Dx);
+            g = Mv[j] - C * Y(P, Q);
             sq += (double)g * (double)g / (double)C;
-        }
-        G[((size_t)b * Hg + pg) * Wg + qg] = g;
-    }
-    // ---- near band (first PBy rows / PBx columns of the plane): LR row/column 0 is edge-replicated into the
-    // pad, so a frame contributes at several coordinates and subtracts different Y samples -- the reference's
-    // sum, frame by frame.  The band's pixels of this tile are enumerated densely so that no lane idles.
-    const int nby = min(max(ma.PBy - p0, 0), TS), nbx = min(max(ma.PBx - q0, 0), TS);
-    const int n_near = (dbg & 4) ? 0 : nby * TS + (TS - nby) * nbx;
-    for (int idx = tid; idx < n_near; idx += 256) {
-        int pr, qc;
-        if (idx < nby * TS) {
-            pr = idx / TS, qc = idx % TS;
-        } else {
-            const int j = idx - nby * TS;
-            pr = nby + j / nbx, qc = j % nbx;
-        }
-        const int pg = p0 + pr, qg = q0 + qc;
-        if (pg >= Hg || qg >= Wg)
-            continue;
-        T g = 0;
-        // (loads are unconditional, from clamped indices, so that they can be issued back to back)
-#pragma unroll 4
-        for (int k = 0; k < N; k++) {
-            const MTap ty = tabY[(size_t)k * Hg + pg], tx = tabX[(size_t)k * Wg + qg];
-            const bool valid = ty.i >= 0 && tx.i >= 0;
-            const T l = lr[(((size_t)b * N + k) * h + max(ty.i, 0)) * w + max(tx.i, 0)];
-            const T y = Y(valid ? ty.rho : pa, valid ? tx.rho : qa);
-            const T e = valid ? l - y : (T)0;
-            g += e;
-            if (valid && ty.rho == pg - ma.Dy && tx.rho == qg - ma.Dx)  // the sample's own (unreplicated) position
-                sq += (double)e * (double)e;
         }
         G[((size_t)b * Hg + pg) * Wg + qg] = g;
     }
@@ -354,8 +412,10 @@ __global__ void __launch_bounds__(256)
 static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
 {
     const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
-    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
-           2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double));
+    const size_t NBmax = 20 * (Hg + Wg);  // near band: PB <= 18 rows + 18 columns of the plane
+    return 2 * align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
+           2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double)) +
+           align_up(NBmax * sizeof(int)) + align_up(NBmax * N * sizeof(NEnt));
 }
 
 template <typename T>
@@ -368,10 +428,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
-    T *pad = ar.take<T>((size_t)B * Hp * Wp);
+    const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
+    T *pad = ar.take<T>((size_t)B * Hp * Wp), *Yb = ar.take<T>((size_t)B * Hp * Wp);
     T *G = ar.take<T>((size_t)B * Hg * Wg), *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
     MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = ar.take<double>(B);
+    int *ncnt = ar.take<int>(NB);
+    NEnt *nent = ar.take<NEnt>((size_t)NB * N);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
@@ -380,6 +443,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         dy.n[q] = q < N ? py.n[q] : 0, dx.n[q] = q < N ? px.n[q] : 0;
     MosaicArgs<T> ma;
     ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB;
+    ma.YBy = py.E + py.PB - 13 + 1, ma.YBx = px.E + px.PB - 13 + 1;  // E - n_min + 1
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
     for (int i = 0; i < 4; i++)
@@ -411,6 +475,10 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         return SRX_E_HIP;
     SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, N, h, w, tabY,
                tabX, Hg, Wg, py.PB, px.PB, Mg, Cg, Vtot);
+    const bool zero_ = py.zero && px.zero;
+    hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, h, w, Hg, Wg, py.PB, px.PB, py.D,
+                       px.D, zero_ ? 1 : 0, H, W, NB, ncnt, nent);
+    SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     if (errors) {
         const int total = B * n_iter;
@@ -428,12 +496,17 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
-        if (zero)
-            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
-                       tabX, lr, N, h, w, G, eo, n_iter, scale, dbg);
-        else
-            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, tabY,
-                       tabX, lr, N, h, w, G, eo, n_iter, scale, dbg);
+        if (zero) {
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
+                       eo, n_iter, scale, dbg);
+            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), B), dim3(256), 0, st, lr, (size_t)N * h * w, pad,
+                       (size_t)H * W, N, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
+        } else {
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
+                       eo, n_iter, scale, dbg);
+            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), B), dim3(256), 0, st, lr, (size_t)N * h * w, Yb,
+                       (size_t)Hp * Wp, N, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
+        }
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr)
         if (zero) {
