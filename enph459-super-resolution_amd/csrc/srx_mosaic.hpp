@@ -205,40 +205,62 @@ __global__ void __launch_bounds__(256)
     ncnt[idx] = cnt;
 }
 
-// G on the near band: the reference's sum, frame by frame, over the frames that land on each pixel
+// G on the near band: the reference's sum, frame by frame, over the frames that land on each pixel.
+// One thread = one band pixel of NEAR_IB consecutive batch items: the pixel's entry list (shared by all
+// items) is read once per entry and its 2 * NEAR_IB operand loads are issued together.
+#define NEAR_IB 8
 template <typename T>
 __global__ void __launch_bounds__(256)
-    k_fwd_near(const T *__restrict__ lr, size_t lr_item, const T *__restrict__ ysrc, size_t y_item, int N, int Hg, int Wg,
-               int PBy, int PBx, int NB, const int *__restrict__ ncnt, const NEnt *__restrict__ nent, T *__restrict__ G,
-               double *__restrict__ errors, int errors_stride, double scale)
+    k_fwd_near(const T *__restrict__ lr, size_t lr_item, const T *__restrict__ ysrc, size_t y_item, int N, int B, int Hg,
+               int Wg, int PBy, int PBx, int NB, const int *__restrict__ ncnt, const NEnt *__restrict__ nent,
+               T *__restrict__ G, double *__restrict__ errors, int errors_stride, double scale)
 {
-    __shared__ double part[4];
-    const int idx = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    double sq = 0.0;
+    __shared__ double part[4][NEAR_IB];
+    const int idx = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * NEAR_IB;
+    double sq[NEAR_IB];
+    T g[NEAR_IB];
+#pragma unroll
+    for (int i = 0; i < NEAR_IB; i++)
+        sq[i] = 0.0, g[i] = 0;
     if (idx < NB) {
-        int p, q;
-        near_px(idx, Wg, PBy, PBx, p, q);
         const int cnt = ncnt[idx];
         const NEnt *ent = nent + (size_t)idx * N;
-        const T *l0 = lr + (size_t)b * lr_item, *y0 = ysrc + (size_t)b * y_item;
-        T g = 0;
         for (int e = 0; e < cnt; e++) {
             const NEnt en = ent[e];
-            const T d = l0[en.off] - y0[en.yoff];
-            g += d;
-            if (en.unc)
-                sq += (double)d * (double)d;
+            T l[NEAR_IB], y[NEAR_IB];
+#pragma unroll
+            for (int i = 0; i < NEAR_IB; i++) {
+                const size_t b = min(b0 + i, B - 1);  // clamped duplicate for a ragged last group; dropped at the store
+                l[i] = lr[b * lr_item + en.off];
+                y[i] = ysrc[b * y_item + en.yoff];
+            }
+#pragma unroll
+            for (int i = 0; i < NEAR_IB; i++) {
+                const T d = l[i] - y[i];
+                g[i] += d;
+                if (en.unc)
+                    sq[i] += (double)d * (double)d;
+            }
         }
-        G[((size_t)b * Hg + p) * Wg + q] = g;
+        int p, q;
+        near_px(idx, Wg, PBy, PBx, p, q);
+#pragma unroll
+        for (int i = 0; i < NEAR_IB; i++)
+            if (b0 + i < B)
+                G[((size_t)(b0 + i) * Hg + p) * Wg + q] = g[i];
     }
-    sq = wave_sum(sq);
-    if ((threadIdx.x & 63) == 0)
-        part[threadIdx.x >> 6] = sq;
+#pragma unroll
+    for (int i = 0; i < NEAR_IB; i++) {
+        const double s = wave_sum(sq[i]);
+        if ((threadIdx.x & 63) == 0)
+            part[threadIdx.x >> 6][i] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && errors) {
-        const double s = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x < NEAR_IB && errors && b0 + threadIdx.x < B) {
+        const int i = threadIdx.x;
+        const double s = part[0][i] + part[1][i] + part[2][i] + part[3][i];
         if (s != 0.0)
-            atomicAdd(&errors[(size_t)b * errors_stride], s * scale);
+            atomicAdd(&errors[(size_t)(b0 + i) * errors_stride], s * scale);
     }
 }
 
@@ -499,13 +521,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         if (zero) {
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
                        eo, n_iter, scale, dbg);
-            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), B), dim3(256), 0, st, lr, (size_t)N * h * w, pad,
-                       (size_t)H * W, N, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
+            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
+                       (size_t)N * h * w, pad, (size_t)H * W, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
         } else {
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
                        eo, n_iter, scale, dbg);
-            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), B), dim3(256), 0, st, lr, (size_t)N * h * w, Yb,
-                       (size_t)Hp * Wp, N, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
+            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
+                       (size_t)N * h * w, Yb, (size_t)Hp * Wp, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
         }
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr)
