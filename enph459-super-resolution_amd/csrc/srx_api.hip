@@ -23,7 +23,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_fwd_near", "k_bwd_mosaic"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_fwd_near", "k_bwd_mosaic", "k_saa_tile"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -322,6 +322,10 @@ static int saa_dispatch(const T *lr, int B, int N, int h, int w, const double *s
     if ((flags & SRX_FLAG_FUSED) && !can_fuse)
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
+        if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::saa_eligible(N, h, w, sh, f)) {
+            g_last_path = "mosaic";
+            return mosaic::saa<T>(lr, B, N, h, w, sh, f, out, ws, wsb, st);
+        }
         g_last_path = "fused";
         return fused::saa<T>(lr, B, N, h, w, sh, f, out, ws, wsb, st);
     }
@@ -389,7 +393,9 @@ size_t srx_backproject_workspace_bytes(int eb, int B, int H, int W) { return bac
 size_t srx_saa_workspace_bytes(int eb, int B, int N, int h, int w, int f)
 {
     size_t a = saa_ws_composed(eb, B, N, h, w, f), b = fused::saa_ws(eb, B, N, h, w, f);
-    return a > b ? a : b;
+    const size_t c = mosaic::saa_ws(eb, B, N, h, w, f);
+    a = a > b ? a : b;
+    return a > c ? a : c;
 }
 
 size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W, int f, unsigned flags)

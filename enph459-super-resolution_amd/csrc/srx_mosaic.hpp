@@ -429,6 +429,115 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------
+// shift_and_add (mono_cal_target/run_sr.py:181-187) for shift sets with a common sub-pixel fraction:
+//   out = (1/N) crop P FIR_f ( sum_k T_{o_k} pad12(zoom(lr_k)) )
+// (P commuted past the per-frame FIRs exactly as in fused::saa; the FIR is then the same for every frame and
+// moves outside the sum, leaving an integer translation T per frame).  One block per output tile: for each
+// frame the needed patch of spline coefficients is staged in LDS, zoomed separably (row pass into LDS, column
+// pass into registers) at the translated, edge-clamped positions and accumulated; then FIR + prefilter run on
+// the tile like in k_bwd_mosaic.  zoom(order=3) semantics (corner-aligned, mirrored taps) come from the same
+// device-built tap tables as srx_zoom_cubic.
+// ---------------------------------------------------------------------------------------
+struct FrameOffsets {
+    int oy[SRX_MAX_FRAMES], ox[SRX_MAX_FRAMES];
+};
+
+template <typename T, int F> struct SaaCfg {
+    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3;  // region edge (odd)
+    static constexpr int PD = (SR + 12) / F + 6;                                          // LR patch edge bound
+    static constexpr int NPX = (SR * SR + 255) / 256;
+};
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256)
+    k_saa_tile(const T *__restrict__ coef, int N, int h, int w, const AxisTap<T> *__restrict__ zy,
+               const AxisTap<T> *__restrict__ zx, FrameOffsets fo, MosaicArgs<T> ma, int H, int W, T inv_n_div,
+               T *__restrict__ out)
+{
+    using C = SaaCfg<T, F>;
+    constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NPX = C::NPX;
+    // LDS: during the frame loop [patch PD*PD | rows PD*SR | zy taps SR | zx taps SR]; afterwards the SR*SR region
+    constexpr int FRAME_WORDS = PD * PD + PD * SR;
+    constexpr int WORDS = FRAME_WORDS > SR * SR ? FRAME_WORDS : SR * SR;
+    __shared__ T lds[WORDS];
+    __shared__ AxisTap<T> ztY[SR], ztX[SR];
+    T *patch = lds, *rows = lds + PD * PD, *reg = lds;
+    const int tid = threadIdx.x;
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    const int pa = max(0, r0 + SRX_NPAD - R), pb = min(Hp, r0 + SRX_NPAD + TS + R);
+    const int qa = max(0, c0 + SRX_NPAD - R), qb = min(Wp, c0 + SRX_NPAD + TS + R);
+    const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;  // W-plane region = v region + 3
+    T acc[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++)
+        acc[j] = 0;
+    for (int k = 0; k < N; k++) {
+        const int oy = fo.oy[k], ox = fo.ox[k];
+        // image rows / columns this frame's translated window covers (edge clamped = the 12-px pad)
+        const int y_lo = min(max(pa + oy - SRX_NPAD, 0), H - 1), y_hi = min(max(pa + nrw - 1 + oy - SRX_NPAD, 0), H - 1);
+        const int x_lo = min(max(qa + ox - SRX_NPAD, 0), W - 1), x_hi = min(max(qa + ncw - 1 + ox - SRX_NPAD, 0), W - 1);
+        if (tid < nrw)
+            ztY[tid] = zy[min(max(pa + tid + oy - SRX_NPAD, 0), H - 1)];
+        else if (tid >= 128 && tid - 128 < ncw)
+            ztX[tid - 128] = zx[min(max(qa + tid - 128 + ox - SRX_NPAD, 0), W - 1)];
+        // LR patch bounds from the first / last tap tables (mirrored indices stay inside [0, h-1])
+        const AxisTap<T> ty0 = zy[y_lo], ty1 = zy[y_hi], tx0 = zx[x_lo], tx1 = zx[x_hi];
+        const int jy0 = min(min(ty0.idx[0], ty0.idx[1]), min(ty0.idx[2], ty0.idx[3]));
+        const int jy1 = max(max(ty1.idx[0], ty1.idx[1]), max(ty1.idx[2], ty1.idx[3]));
+        const int jx0 = min(min(tx0.idx[0], tx0.idx[1]), min(tx0.idx[2], tx0.idx[3]));
+        const int jx1 = max(max(tx1.idx[0], tx1.idx[1]), max(tx1.idx[2], tx1.idx[3]));
+        const int npy = jy1 - jy0 + 1, npx = jx1 - jx0 + 1;  // <= PD
+        const T *src = coef + ((size_t)b * N + k) * h * w;
+        for (int idx = tid; idx < npy * npx; idx += 256) {
+            const int py = idx / npx, px = idx - py * npx;
+            patch[py * PD + px] = src[(size_t)(jy0 + py) * w + jx0 + px];
+        }
+        __syncthreads();
+        // row pass: rows[py][cc] = sum_j zx[x(cc)].w[j] * patch[py][idx[j]]
+        for (int idx = tid; idx < npy * ncw; idx += 256) {
+            const int py = idx / ncw, cc = idx - py * ncw;
+            const AxisTap<T> t = ztX[cc];
+            const T *pr = patch + py * PD - jx0;
+            rows[py * SR + cc] = t.w[0] * pr[t.idx[0]] + t.w[1] * pr[t.idx[1]] + t.w[2] * pr[t.idx[2]] + t.w[3] * pr[t.idx[3]];
+        }
+        __syncthreads();
+        // column pass, accumulated over frames: up_k(y(rr), x(cc)) = sum_i zy[y].w[i] * rows[idx[i]][cc]
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const int idx = min(tid + 256 * j, nrw * ncw - 1);  // clamped duplicate for the ragged tail; dropped below
+            const int rr = idx / ncw, cc = idx - rr * ncw;
+            const AxisTap<T> t = ztY[rr];
+            const T *pc = rows + cc - jy0 * SR;
+            acc[j] += t.w[0] * pc[t.idx[0] * SR] + t.w[1] * pc[t.idx[1] * SR] + t.w[2] * pc[t.idx[2] * SR] +
+                      t.w[3] * pc[t.idx[3] * SR];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int idx = tid + 256 * j;
+        if (idx < nrw * ncw) {
+            const int rr = idx / ncw, cc = idx - rr * ncw;
+            reg[rr * LD + cc] = acc[j];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < ncw; c += 256)
+        fused::walk_line<T, LD, 1>(reg + c, nrw, pa == 0, ma.wfy);
+    __syncthreads();
+    const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
+    for (int r = r_lo + tid; r < r_hi; r += 256)
+        fused::walk_line<T, 1, 1>(reg + r * LD, ncw, qa == 0, ma.wfx);
+    __syncthreads();
+    for (int idx = tid; idx < TS * TS; idx += 256) {
+        const int r = r0 + idx / TS, c = c0 + idx % TS;
+        if (r < H && c < W)
+            out[((size_t)b * H + r) * W + c] = reg[(r + SRX_NPAD - pa) * LD + (c + SRX_NPAD - qa)] / inv_n_div;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
@@ -544,6 +653,66 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         }
 #undef SRX_BWDM
     }
+    return SRX_OK;
+}
+
+
+static inline bool saa_eligible(int N, int h, int w, const double *sh, int f)
+{
+    if (getenv("SRX_NO_MOSAIC") || !fused::saa_eligible(N, h, w, sh, f) || f < 2 || f > 4 || h < 8 || w < 8)
+        return false;
+    AxisPlan a;
+    return plan_axis(N, sh, 0, f, a) && plan_axis(N, sh, 1, f, a);
+}
+
+static inline size_t saa_ws(int eb, int B, int N, int h, int w, int f)
+{
+    return 2 * align_up((size_t)B * N * h * w * eb) + 2 * align_up((size_t)(h > w ? h : w) * f * sizeof(AxisTap<double>));
+}
+
+template <typename T>
+static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f, T *out, void *ws, size_t wsb,
+               hipStream_t st)
+{
+    if ((long)B * N > 65535)
+        return SRX_E_UNSUPPORTED;
+    const int H = h * f, W = w * f;
+    AxisPlan py, px;
+    if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
+        return SRX_E_UNSUPPORTED;
+    Arena ar(ws, wsb);
+    T *coef = ar.take<T>((size_t)B * N * h * w), *cscr = ar.take<T>((size_t)B * N * h * w);
+    AxisTap<T> *zy = ar.take<AxisTap<T>>(H), *zx = ar.take<AxisTap<T>>(W);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SRX_E_HIP;
+    SRX_TRY(prefilter2d(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+    SRX_TRY(build_taps(zy, H, h, TAP_ZOOM, 1, H > 1 ? (double)(h - 1) / (double)(H - 1) : 1.0, st));
+    SRX_TRY(build_taps(zx, W, w, TAP_ZOOM, 1, W > 1 ? (double)(w - 1) / (double)(W - 1) : 1.0, st));
+    FrameOffsets fo;
+    MosaicArgs<T> ma;
+    for (int q = 0; q < SRX_MAX_FRAMES; q++) {
+        // shift(+d): the padded FIR reads U[p + floor(-d) - 1 + a]; -d = (-n - 1) + (1 - delta), or -n when delta = 0
+        fo.oy[q] = q < N ? -py.n[q] - (py.zero ? 1 : 2) : 0;
+        fo.ox[q] = q < N ? -px.n[q] - (px.zero ? 1 : 2) : 0;
+    }
+    ma.Dy = ma.Dx = ma.PBy = ma.PBx = ma.YBy = ma.YBx = 0;
+    double wv[4];
+    fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wfy[i] = ma.wby[i] = (T)wv[i];
+    fused::host_weights(px.zero ? 0.0 : 1.0 - px.delta, wv);
+    for (int i = 0; i < 4; i++)
+        ma.wfx[i] = ma.wbx[i] = (T)wv[i];
+    constexpr int TS = TileCfg<T>::T_HR;
+    const dim3 grid(cdiv(W, TS), cdiv(H, TS), B);
+    if (f == 4)
+        SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 4>), grid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, out);
+    else if (f == 3)
+        SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 3>), grid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, out);
+    else
+        SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 2>), grid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, out);
     return SRX_OK;
 }
 

@@ -366,7 +366,9 @@ __global__ void __launch_bounds__(64) k_build_taps(AxisTap<T> *__restrict__ tab,
                     idx = s2 - idx;
             }
         }
-        t.idx[k] = valid ? (int)idx : 0;
+        // a sample outside the array (cval 0) keeps in-range, monotone indices with zero weights, so that tile
+        // kernels can size their source patches from the first / last table entries
+        t.idx[k] = valid ? (int)idx : (int)min(max(start + k, 0L), (long)len - 1);
         t.w[k] = valid ? (T)w[k] : (T)0;
     }
     tab[i] = t;

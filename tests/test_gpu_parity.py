@@ -249,8 +249,11 @@ def test_fused_path_vs_oracle(prec, cfg):
     finally:
         O.set_threads(1)
     saa = S.shift_and_add(list(lr), shifts, f)
-    assert S.last_path() == "fused"
+    assert S.last_path() == want
     close(saa, saa_o, PRIM_TOL[prec])
+    saa_p = S.shift_and_add_batched(lr[None], shifts, f, flags=S.FLAG_PER_FRAME)
+    assert S.last_path() == "fused"
+    close(saa_p[0].cpu().numpy(), saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
     assert S.last_path() == want
     close(hr, hr_o, IBP_TOL[prec])
