@@ -139,6 +139,21 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// XCD-aware block remap (speed only, never correctness): hardware deals consecutive workgroup ids round-robin
+// over the 8 XCDs, each with its own 4 MiB L2.  Re-number so that the blocks one XCD receives are CONSECUTIVE
+// tiles (x fastest, then y, then batch item): neighbouring tiles -- which share halos -- then hit the same L2.
+// Bijective for any grid size (cdna guide, T1).
+__device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bx = (int)(id % gx);
+    by = (int)((id / gx) % gy);
+    bz = (int)(id / (gx * gy));
+}
+
 // cubic B-spline weights for fractional offset t in [0, 1), computed as scipy does (ni_splines.c)
 __device__ __forceinline__ void bspline3_weights(double t, double w[4])
 {

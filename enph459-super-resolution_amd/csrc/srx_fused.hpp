@@ -246,8 +246,10 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
 {
     __shared__ T tile[(SRX_BT_H + 6) * SRX_BT_LDW];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c0 = blockIdx.x * SRX_BT_W, r0 = blockIdx.y * SRX_BT_H;
-    const T *src = hr + (size_t)blockIdx.z * H * W;
+    int bx, by, bz;
+    xcd_block(bx, by, bz);
+    const int c0 = bx * SRX_BT_W, r0 = by * SRX_BT_H;
+    const T *src = hr + (size_t)bz * H * W;
     {
         // (32+6) x (64+6) source tile, zero outside the image: all loads first (clamped addresses), then the stores
         constexpr int RPW = (SRX_BT_H + 6 + 3) / 4;  // 10 rows per wave
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     if (c >= W)
         return;
     if (!PAD) {  // plain [H, W] plane; consumers read it through load_region_pad
-        T *out = bpad + (size_t)blockIdx.z * H * W;
+        T *out = bpad + (size_t)bz * H * W;
 #pragma unroll
         for (int o = 0; o < 8; o++) {
             const int r = r0 + ty * 8 + o;
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
         return;
     }
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    T *dst = bpad + (size_t)blockIdx.z * Hp * Wp;
+    T *dst = bpad + (size_t)bz * Hp * Wp;
     const int clo = c == 0 ? 0 : c + SRX_NPAD, chi = c == W - 1 ? Wp - 1 : c + SRX_NPAD;
 #pragma unroll
     for (int o = 0; o < 8; o++) {
@@ -602,7 +604,9 @@ __global__ void __launch_bounds__(256)
     __shared__ T reg[FR * LD];
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.y * th, j0 = blockIdx.x * tw, b = blockIdx.z;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int i0 = by * th, j0 = bx * tw;
     const int i1 = min(i0 + th, h), j1 = min(j0 + tw, w);
     const int pa = max(0, f * i0 + omin_y - R), pb = min(Hp - 1, f * (i1 - 1) + omax_y + 3 + R);
     const int qa = max(0, f * j0 + omin_x - R), qb = min(Wp - 1, f * (j1 - 1) + omax_x + 3 + R);
@@ -734,7 +738,9 @@ __global__ void __launch_bounds__(256)
     __shared__ T reg[BR * LD];
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int r0 = by * TS, c0 = bx * TS;
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
     const int nr = pb - pa, nc = qb - qa;

@@ -279,7 +279,9 @@ __global__ void __launch_bounds__(256)
     __shared__ T reg[ZERO ? 1 : FR * LD];
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.y * TS, q0 = blockIdx.x * TS, b = blockIdx.z;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int p0 = by * TS, q0 = bx * TS;
     const int H = Hp - 2 * SRX_NPAD, W = Wp - 2 * SRX_NPAD;
     const T *src = bimg + (size_t)b * H * W;  // plain blurred plane; its 12-px edge extension is applied on the fly
     // far-field operands of this thread's TS*TS/256 pixels, fetched up front (clamped addresses) so that their
@@ -360,13 +362,15 @@ __global__ void __launch_bounds__(256)
 template <typename T, bool ZERO, bool SEP>
 __global__ void __launch_bounds__(256)
     k_bwd_mosaic(const T *__restrict__ G, int Hg, int Wg, MosaicArgs<T> ma, int H, int W, Kernel7<T> kt, T step, T n,
-                 const T *__restrict__ hr_in, T *__restrict__ hr_out)
+                 const T *__restrict__ hr_in, T *__restrict__ hr_out, int dbg)
 {
     constexpr int R = ZERO ? 0 : TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 3;  // odd
     __shared__ T reg[(BR + 3) * LD];
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int r0 = by * TS, c0 = bx * TS;
     const T *src = G + (size_t)b * Hg * Wg;
     // padded rows of c' the 7x7 window of this tile reads: [r0+9, r0+TS+15); R more on each side for the recursion
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
@@ -386,10 +390,12 @@ __global__ void __launch_bounds__(256)
     } else {
         fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
         __syncthreads();
+        if (!(dbg & 16))
         for (int c = tid; c < nc + 3; c += 256)
             fused::walk_line<T, LD, 1>(reg + c, nr + 3, pa == 0, ma.wby);
         __syncthreads();
         const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
+        if (!(dbg & 32))
         for (int r = r_lo + tid; r < r_hi; r += 256)
             fused::walk_line<T, 1, 1>(reg + r * LD, nc + 3, qa == 0, ma.wbx);
         __syncthreads();
@@ -412,7 +418,7 @@ __global__ void __launch_bounds__(256)
     const size_t base = (size_t)b * H * W;
 #pragma unroll
     for (int half = 0; half < TS / 32; half++) {
-        if (lane < TS) {
+        if (lane < TS && !(dbg & 64)) {
             T a8[8];
             corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
 #pragma unroll
@@ -464,7 +470,9 @@ __global__ void __launch_bounds__(256)
     T *patch = lds, *rows = lds + PD * PD, *reg = lds;
     const int tid = threadIdx.x;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
-    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS, b = blockIdx.z;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int r0 = by * TS, c0 = bx * TS;
     const int pa = max(0, r0 + SRX_NPAD - R), pb = min(Hp, r0 + SRX_NPAD + TS + R);
     const int qa = max(0, c0 + SRX_NPAD - R), qb = min(Wp, c0 + SRX_NPAD + TS + R);
     const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;  // W-plane region = v region + 3
@@ -639,7 +647,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        (size_t)N * h * w, Yb, (size_t)Hp * Wp, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
         }
 #define SRX_BWDM(Z_, S_)                                                                                             \
-    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr)
+    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, dbg)
         if (zero) {
             if (sep)
                 SRX_BWDM(true, true);
