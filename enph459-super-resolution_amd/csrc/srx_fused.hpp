@@ -490,7 +490,14 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
     const int n = MODE == 1 ? n_in - 3 : n_in;
     const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
     T prev = 0;
-    if (edge) {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
+    if (!edge) {
+        // interior cut: start from the steady state of a constant signal v[0] (c+ = 6 v / (1 - z)) rather than
+        // from zero, so the start-up error is |z|^R times the signal's DEVIATION from v[0], not its magnitude
+        T v0 = line[0];
+        if (MODE == 1)
+            v0 = w0 * line[0] + w1 * line[S] + w2 * line[2 * S] + w3 * line[3 * S];
+        prev = (T)6 * v0 / ((T)1 - z);
+    } else {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
         T zi = 1, acc = 0;
         const int kk = min(K, n);
         T g0 = line[0], g1 = MODE == 1 ? line[S] : (T)0, g2 = MODE == 1 ? line[2 * S] : (T)0;
