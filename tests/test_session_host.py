@@ -1,0 +1,53 @@
+"""Host-side pieces of the session driver (no GPU): measured-PSF estimation against the kernel the
+reference's load_measured_psf (mono_cal_target/run_sr.py:114-152) produced from the same pinhole frames, the
+shift tables and the discovery rules."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+session = pytest.importorskip("sr_mi355x.session")
+
+
+def test_measured_psf_matches_reference():
+    g = load_golden("pinholes.npz")
+    k = session.psf_from_pinhole_images(list(g["windows"]))
+    assert k.shape == (7, 7)
+    assert np.abs(k - g["psf_m"]).max() < 1e-15
+    assert abs(k.sum() - 1.0) < 1e-15 and (k >= 0).all()
+    assert not np.allclose(k, k[::-1, ::-1])  # asymmetric: the flipped kernel of back_project is not a no-op
+
+
+def test_psf_skips_peaks_near_the_edge():
+    g = load_golden("pinholes.npz")
+    wins = list(g["windows"])
+    bad = np.zeros((41, 41))
+    bad[2, 20] = 255.0  # peak closer than 9 px to the border
+    k = session.psf_from_pinhole_images(wins + [bad])
+    assert np.abs(k - g["psf_m"]).max() < 1e-15
+    with pytest.raises(FileNotFoundError):
+        session.psf_from_pinhole_images([bad])
+
+
+def test_shift_tables_match_reference_constants():
+    assert [s for _, s in session.IMAGE_SHIFTS] == [(0.0, 0.0), (0.5, -0.5), (0.5, 0.5), (-0.5, -0.5), (-0.5, 0.5)]
+    assert session.CORNER_SHIFTS == [(0.5, -0.5), (0.5, 0.5), (-0.5, -0.5), (-0.5, 0.5)]
+    assert session.IBP_ITERATIONS == {"mono_cal_target": 80, "rgb_cal_target": 50, "mono_barcodes": 80,
+                                      "rgb_barcodes": 80}
+
+
+def test_discovery(tmp_path):
+    (tmp_path / "a").mkdir()
+    (tmp_path / "a" / "center.png").write_bytes(b"")
+    (tmp_path / "b").mkdir()
+    (tmp_path / "b" / "corner0_rep00.png").write_bytes(b"")
+    (tmp_path / "b" / "metadata.json").write_text(json.dumps({}))
+    (tmp_path / "c.txt").write_text("x")
+    assert [os.path.basename(p) for p in session.discover_sessions(str(tmp_path), "mono_cal_target")] == ["a"]
+    assert [os.path.basename(p) for p in session.discover_sessions(str(tmp_path), "rgb_cal_target")] == ["b"]
+    assert [os.path.basename(p) for p in session.discover_sessions(str(tmp_path), "mono_barcodes")] == ["b"]
+    assert session.detect_kind(str(tmp_path / "a")) == "mono_cal_target"
+    assert session.detect_kind(str(tmp_path / "b")) is None

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of
+`bench.py --steps 1 --warmup 0 --iters 4 --no-cpu-baseline --no-roofline` into profiles/traffic.json: HBM bytes
+per launch of each fused-path kernel.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports
+exactly half of the bytes actually fetched -- calibrated here on our own access pattern (4 B/lane loads):
+k_blur_pad reads one 268 435 456-byte plane per launch and FETCH_SIZE says 131 116 KiB = 0.5002 of it, while
+its WRITE_SIZE (262 144 KiB) is exact.  So bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+
+usage: collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <workload tag> [out.json]
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
+            acc[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"workload": sys.argv[3], "unit": "bytes per launch",
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+           "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
+                             "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    dst = sys.argv[4] if len(sys.argv) > 4 else "profiles/traffic.json"
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -183,6 +183,18 @@ def main():
     d["psf_g"] = psf_g
     np.savez_compressed(os.path.join(OUT, "real_crops.npz"), **d)
 
+    # ---------------- measured PSF: windows around the pinhole peaks + the reference's kernel -----------
+    psf_dir = os.path.join(REF, "calibration_beam_shift", "data")
+    wins = []
+    for sweep in sorted(os.listdir(psf_dir)):
+        path = os.path.join(psf_dir, sweep, "pos4_(0,0).png")
+        if os.path.isdir(os.path.join(psf_dir, sweep)) and os.path.exists(path):
+            img = np.array(Image.open(path))
+            pr, pc = np.unravel_index(img.argmax(), img.shape)
+            assert 20 <= pr < img.shape[0] - 20 and 20 <= pc < img.shape[1] - 20
+            wins.append(img[pr - 20:pr + 21, pc - 20:pc + 21].copy())  # 41x41, same arg-max as the full frame
+    np.savez_compressed(os.path.join(OUT, "pinholes.npz"), windows=np.stack(wins), psf_m=psf_m)
+
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as fp:
         json.dump({"generated_by": "tools/make_golden.py", "reference": "benedikthoward/ENPH459-Super-Resolution",
                    "functions": "mono_cal_target/run_sr.py:157-209 (+rgb_cal_target loaders) imported by path",
