@@ -216,7 +216,9 @@ __global__ void __launch_bounds__(256)
                T *__restrict__ G, double *__restrict__ errors, int errors_stride, double scale)
 {
     __shared__ double part[4][NEAR_IB];
-    const int idx = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * NEAR_IB;
+    int bx, by, bz;
+    xcd_block(bx, by, bz);  // the ~34 blocks of one item group share an XCD: replicated samples hit its L2
+    const int idx = bx * 256 + threadIdx.x, b0 = by * NEAR_IB;
     double sq[NEAR_IB];
     T g[NEAR_IB];
 #pragma unroll
