@@ -482,21 +482,101 @@ template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
 // S = element stride, a compile-time constant: with a run-time stride hipcc must assume that the store of
 // step i aliases the load of step i+1 and serialises one LDS round trip (~150 cycles) per step.  Here 8
 // samples are read, run through the serial recursion in registers and written back per trip.
+template <typename T> struct WalkState {
+    T prev;        // causal state c+[i-1]
+    T g0, g1, g2;  // MODE 1: the three newest FIR inputs
+    T next;        // anticausal state c[i+1]
+    T a1, a2, a3;  // MODE 2: c[i+1], c[i+2], c[i+3]
+};
+
+// causal steps i = i0 .. i1-1 reading the line itself
 template <typename T, int S, int MODE>
-__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w)
+__device__ __forceinline__ void causal_run(T *__restrict__ line, int i0, int i1, WalkState<T> &st, T w0, T w1, T w2, T w3)
 {
-    constexpr int U = 8, K = Warmup<T>::n;
-    const T z = pole<T>(), zfin = z / (z - (T)1);
-    const int n = MODE == 1 ? n_in - 3 : n_in;
-    const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
-    T prev = 0;
+    constexpr int U = 8, O = MODE == 1 ? 3 : 0;
+    const T z = pole<T>();
+    int base = i0;
+    for (; base + U <= i1; base += U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = line[(base + u + O) * S];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            T v = x[u];
+            if (MODE == 1) {
+                v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * x[u];
+                st.g0 = st.g1, st.g1 = st.g2, st.g2 = x[u];
+            }
+            st.prev = (T)6 * v + z * st.prev;
+            x[u] = st.prev;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            line[(base + u) * S] = x[u];
+    }
+    for (; base < i1; base++) {
+        T v = line[(base + O) * S];
+        if (MODE == 1) {
+            const T g3 = v;
+            v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * g3;
+            st.g0 = st.g1, st.g1 = st.g2, st.g2 = g3;
+        }
+        st.prev = (T)6 * v + z * st.prev;
+        line[base * S] = st.prev;
+    }
+}
+
+// anticausal steps i = ihi .. ilo (downwards), reading c+ from the line
+template <typename T, int S, int MODE>
+__device__ __forceinline__ void anticausal_run(T *__restrict__ line, int ihi, int ilo, WalkState<T> &st, T w0, T w1, T w2, T w3)
+{
+    constexpr int U = 8;
+    const T z = pole<T>();
+    int i = ihi;
+    for (; i - (U - 1) >= ilo; i -= U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = line[(i - u) * S];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            st.next = z * (st.next - x[u]);
+            if (MODE == 2) {
+                x[u] = w0 * st.next + w1 * st.a1 + w2 * st.a2 + w3 * st.a3;  // a valid FIR output for i-u <= n-4
+                st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
+            } else {
+                x[u] = st.next;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            line[(i - u) * S] = x[u];
+    }
+    for (; i >= ilo; i--) {
+        st.next = z * (st.next - line[i * S]);
+        if (MODE == 2) {
+            line[i * S] = w0 * st.next + w1 * st.a1 + w2 * st.a2 + w3 * st.a3;
+            st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
+        } else {
+            line[i * S] = st.next;
+        }
+    }
+}
+
+// start of the causal recursion at the beginning of a line
+template <typename T, int S, int MODE>
+__device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, bool edge, WalkState<T> &st, T w0, T w1, T w2, T w3)
+{
+    constexpr int K = Warmup<T>::n;
+    const T z = pole<T>();
     if (!edge) {
         // interior cut: start from the steady state of a constant signal v[0] (c+ = 6 v / (1 - z)) rather than
         // from zero, so the start-up error is |z|^R times the signal's DEVIATION from v[0], not its magnitude
         T v0 = line[0];
         if (MODE == 1)
             v0 = w0 * line[0] + w1 * line[S] + w2 * line[2 * S] + w3 * line[3 * S];
-        prev = (T)6 * v0 / ((T)1 - z);
+        st.prev = (T)6 * v0 / ((T)1 - z);
     } else {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
         T zi = 1, acc = 0;
         const int kk = min(K, n);
@@ -513,76 +593,137 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
             acc += zi * v;
             zi *= z;
         }
-        prev = (T)6 * acc;
+        st.prev = (T)6 * acc;
     }
-    // ---- causal ----
-    T g0 = 0, g1 = 0, g2 = 0;
     if (MODE == 1)
-        g0 = line[0], g1 = line[S], g2 = line[2 * S];
-    int base = 0;
-    for (; base + U <= n; base += U) {
-        T x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            x[u] = line[(base + u + (MODE == 1 ? 3 : 0)) * S];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            T v = x[u];
-            if (MODE == 1) {
-                v = w0 * g0 + w1 * g1 + w2 * g2 + w3 * x[u];
-                g0 = g1, g1 = g2, g2 = x[u];
-            }
-            prev = (T)6 * v + z * prev;
-            x[u] = prev;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            line[(base + u) * S] = x[u];
-    }
-    for (; base < n; base++) {
-        T v = line[(base + (MODE == 1 ? 3 : 0)) * S];
-        if (MODE == 1) {
-            const T g3 = v;
-            v = w0 * g0 + w1 * g1 + w2 * g2 + w3 * g3;
-            g0 = g1, g1 = g2, g2 = g3;
-        }
-        prev = (T)6 * v + z * prev;
-        line[base * S] = prev;
-    }
-    // ---- anticausal ----
-    T next = prev * zfin;
-    T a1 = next, a2 = 0, a3 = 0;  // c[i+1], c[i+2], c[i+3]
+        st.g0 = line[0], st.g1 = line[S], st.g2 = line[2 * S];
+}
+
+template <typename T, int S, int MODE>
+__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w)
+{
+    const T z = pole<T>();
+    const int n = MODE == 1 ? n_in - 3 : n_in;
+    const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
+    WalkState<T> st;
+    st.g0 = st.g1 = st.g2 = 0;
+    causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
+    causal_run<T, S, MODE>(line, 0, n, st, w0, w1, w2, w3);
+    st.next = st.prev * (z / (z - (T)1));
+    st.a1 = st.next, st.a2 = 0, st.a3 = 0;
     if (MODE != 2)
-        line[(n - 1) * S] = next;
-    int i = n - 2;
-    for (; i - (U - 1) >= 0; i -= U) {
-        T x[U];
+        line[(n - 1) * S] = st.next;
+    anticausal_run<T, S, MODE>(line, n - 2, 0, st, w0, w1, w2, w3);
+}
+
+// The same pass over `nlines` (<= 128) lines with TWO threads per line (256-thread block, barriers inside): thread
+// (line, seg) owns outputs [0, mid) or [mid, n).  The second half starts its causal recursion R samples early and
+// the first half its anticausal recursion R samples late, both from values pre-loaded into registers before the
+// other half may overwrite them -- the same |z|^R start-up error the tile edges already have.  Halves the serial
+// chain, which is what bounds this phase (2 of a block's 4 waves used to walk, 2 idled at the barrier).
+template <typename T, int S, int MODE, int R>
+__device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pitch, int nlines, int n_in, bool edge,
+                                               const T *__restrict__ w, int tid)
+{
+    constexpr int O = MODE == 1 ? 3 : 0;
+    const T z = pole<T>(), zfin = z / (z - (T)1);
+    const int n = MODE == 1 ? n_in - 3 : n_in;
+    const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
+    const int lineid = tid & 127, seg = tid >> 7;
+    const bool active = lineid < nlines;
+    T *line = base + (active ? lineid : 0) * line_pitch;
+    if (n < 4 * R + 16) {  // too short to split (block-uniform): one thread per line
+        if (active && seg == 0)
+            walk_line<T, S, MODE>(line, n_in, edge, w);
+        __syncthreads();
+        return;
+    }
+    const int mid = (n / 2) & ~7;
+    WalkState<T> st;
+    st.g0 = st.g1 = st.g2 = 0;
+    T pre[R + 3];
+    // ---- A: inputs the other half is about to overwrite ----
+    if (seg == 1) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            x[u] = line[(i - u) * S];
+        for (int j = 0; j < R + O; j++)
+            pre[j] = line[(mid - R + j) * S];
+    } else if (MODE == 1) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            next = z * (next - x[u]);
-            if (MODE == 2) {
-                x[u] = w0 * next + w1 * a1 + w2 * a2 + w3 * a3;  // a valid FIR output for i-u <= n-4
-                a3 = a2, a2 = a1, a1 = next;
-            } else {
-                x[u] = next;
+        for (int j = 0; j < 3; j++)
+            pre[j] = line[(mid + j) * S];
+    }
+    __syncthreads();
+    // ---- B: causal ----
+    if (active) {
+        if (seg == 0) {
+            causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
+            causal_run<T, S, MODE>(line, 0, mid - 8, st, w0, w1, w2, w3);
+            // last 8 outputs: for MODE 1 the three newest FIR inputs come from registers
+            T x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                x[u] = (MODE == 1 && u >= 5) ? pre[u - 5] : line[(mid - 8 + u + O) * S];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                T v = x[u];
+                if (MODE == 1) {
+                    v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * x[u];
+                    st.g0 = st.g1, st.g1 = st.g2, st.g2 = x[u];
+                }
+                st.prev = (T)6 * v + z * st.prev;
+                x[u] = st.prev;
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            line[(i - u) * S] = x[u];
-    }
-    for (; i >= 0; i--) {
-        next = z * (next - line[i * S]);
-        if (MODE == 2) {
-            line[i * S] = w0 * next + w1 * a1 + w2 * a2 + w3 * a3;
-            a3 = a2, a2 = a1, a1 = next;
+            for (int u = 0; u < 8; u++)
+                line[(mid - 8 + u) * S] = x[u];
         } else {
-            line[i * S] = next;
+            // warm-up over the R pre-loaded samples [mid-R, mid), steady-state start
+            if (MODE == 1) {
+                st.g0 = pre[0], st.g1 = pre[1], st.g2 = pre[2];
+                st.prev = (T)6 * (w0 * pre[0] + w1 * pre[1] + w2 * pre[2] + w3 * pre[3]) / ((T)1 - z);
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const T v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * pre[j + 3];
+                    st.g0 = st.g1, st.g1 = st.g2, st.g2 = pre[j + 3];
+                    st.prev = (T)6 * v + z * st.prev;
+                }
+            } else {
+                st.prev = (T)6 * pre[0] / ((T)1 - z);
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    st.prev = (T)6 * pre[j] + z * st.prev;
+            }
+            causal_run<T, S, MODE>(line, mid, n, st, w0, w1, w2, w3);
         }
     }
+    __syncthreads();
+    // ---- C: the first half pre-loads c+[mid, mid+R) before the second half overwrites it ----
+    if (seg == 0) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            pre[j] = line[(mid + j) * S];
+    }
+    __syncthreads();
+    // ---- D: anticausal ----
+    if (active) {
+        if (seg == 1) {
+            st.next = st.prev * zfin;
+            st.a1 = st.next, st.a2 = 0, st.a3 = 0;
+            if (MODE != 2)
+                line[(n - 1) * S] = st.next;
+            anticausal_run<T, S, MODE>(line, n - 2, mid, st, w0, w1, w2, w3);
+        } else {
+            st.next = pre[R - 1] * zfin;
+            st.a1 = st.next, st.a2 = 0, st.a3 = 0;
+#pragma unroll
+            for (int j = R - 2; j >= 0; j--) {
+                st.next = z * (st.next - pre[j]);
+                st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
+            }
+            anticausal_run<T, S, MODE>(line, mid - 1, 0, st, w0, w1, w2, w3);
+        }
+    }
+    __syncthreads();
 }
 
 // in-place 2-D prefilter of an LDS region [nr x nc], row stride LD (odd: conflict-free row walks).
@@ -591,12 +732,9 @@ template <typename T, int NT, int LD>
 __device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, bool top_edge, bool left_edge, int tid, int r_lo,
                                            int r_hi)
 {
-    for (int c = tid; c < nc; c += NT)
-        walk_line<T, LD, 0>(reg + c, nr, top_edge, nullptr);
-    __syncthreads();
-    for (int r = r_lo + tid; r < r_hi; r += NT)
-        walk_line<T, 1, 0>(reg + r * LD, nc, left_edge, nullptr);
-    __syncthreads();
+    static_assert(NT == 256, "walk_pass_2seg assumes a 256-thread block");
+    walk_pass_2seg<T, LD, 0, TileCfg<T>::R>(reg, 1, nc, nr, top_edge, nullptr, tid);
+    walk_pass_2seg<T, 1, 0, TileCfg<T>::R>(reg + r_lo * LD, LD, r_hi - r_lo, nc, left_edge, nullptr, tid);
 }
 
 // FWD: err[b,k,i,j] = lr[b,k,i,j] - (F_k P bpad)[f i, f j];  errors[b] += sum err^2 * scale.

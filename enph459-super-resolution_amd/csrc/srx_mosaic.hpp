@@ -306,15 +306,10 @@ __global__ void __launch_bounds__(256)
         if (nr > 3 && nc > 3) {
             fused::load_region_pad<T, FR, FR>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
-            if (!(dbg & 1))
-            for (int c = tid; c < nc; c += 256)
-                fused::walk_line<T, LD, 2>(reg + c, nr, pa == 0, ma.wfy);
-            __syncthreads();
+            fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid);
             // rows of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS)
             const int r_lo = max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
-            if (!(dbg & 2))
-            for (int r = r_lo + tid; r < r_hi; r += 256)
-                fused::walk_line<T, 1, 2>(reg + r * LD, nc, qa == 0, ma.wfx);
+            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc, qa == 0, ma.wfx, tid);
         }
         __syncthreads();
     }
@@ -392,15 +387,10 @@ __global__ void __launch_bounds__(256)
     } else {
         fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
         __syncthreads();
-        if (!(dbg & 16))
-        for (int c = tid; c < nc + 3; c += 256)
-            fused::walk_line<T, LD, 1>(reg + c, nr + 3, pa == 0, ma.wby);
-        __syncthreads();
+        constexpr int RW = TileCfg<T>::R;
+        fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid);
         const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
-        if (!(dbg & 32))
-        for (int r = r_lo + tid; r < r_hi; r += 256)
-            fused::walk_line<T, 1, 1>(reg + r * LD, nc + 3, qa == 0, ma.wbx);
-        __syncthreads();
+        fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid);
     }
     // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
     if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
@@ -533,13 +523,9 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    for (int c = tid; c < ncw; c += 256)
-        fused::walk_line<T, LD, 1>(reg + c, nrw, pa == 0, ma.wfy);
-    __syncthreads();
+    fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid);
     const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
-    for (int r = r_lo + tid; r < r_hi; r += 256)
-        fused::walk_line<T, 1, 1>(reg + r * LD, ncw, qa == 0, ma.wfx);
-    __syncthreads();
+    fused::walk_pass_2seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid);
     for (int idx = tid; idx < TS * TS; idx += 256) {
         const int r = r0 + idx / TS, c = c0 + idx % TS;
         if (r < H && c < W)
