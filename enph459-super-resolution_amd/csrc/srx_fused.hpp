@@ -181,11 +181,11 @@ __device__ __forceinline__ void corr7_strip8(const T *tile, int tx, int ty, cons
 // of 64 lanes: wave w takes rows w, w+4, ...; lanes take columns.  Loads are issued in batches of 8 rows
 // before the first LDS store, from clamped (always valid) addresses -- a per-element guarded load makes
 // hipcc wait for each load in turn, which was the single largest cost of the first tile kernels.
-template <typename T, int MAXR, int MAXC>
+template <typename T, int MAXR, int MAXC, int BATCH = 8>
 __device__ __forceinline__ void load_region(T *__restrict__ reg, int ld, const T *__restrict__ src, size_t pitch, int nr,
                                             int nc, int wave, int lane)
 {
-    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64, BATCH = 8;
+    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64;
 #pragma unroll
     for (int j0 = 0; j0 < RPW; j0 += BATCH) {
         T v[BATCH][CPL];
@@ -210,11 +210,11 @@ __device__ __forceinline__ void load_region(T *__restrict__ reg, int ld, const T
 // Same, but the source is an UNPADDED image plane [H, W] read as its 12-px edge-replicated extension: region cell
 // (rr, cc) is padded coordinate (pa + rr, qa + cc) = image pixel (clamp(pa+rr-12), clamp(qa+cc-12)).  SciPy's
 // np.pad(mode='edge') is thus never materialised on the iteration path.
-template <typename T, int MAXR, int MAXC>
+template <typename T, int MAXR, int MAXC, int BATCH = 8>
 __device__ __forceinline__ void load_region_pad(T *__restrict__ reg, int ld, const T *__restrict__ img, int H, int W,
                                                 int pa, int qa, int nr, int nc, int wave, int lane)
 {
-    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64, BATCH = 8;
+    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64;
     int col[CPL];
 #pragma unroll
     for (int cc = 0; cc < CPL; cc++)

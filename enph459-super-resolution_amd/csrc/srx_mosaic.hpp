@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256)
         const int pb = min(Hp, p0 - ma.Dy + TS + 3 + R), qb = min(Wp, q0 - ma.Dx + TS + 3 + R);
         const int nr = pb - pa, nc = qb - qa;  // > 3 for every tile that holds a contributing pixel
         if (nr > 3 && nc > 3) {
-            fused::load_region_pad<T, FR, FR>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
+            fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? 12 : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
             fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid);
             // rows of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS)
@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(256)
                     : reg[(P - pa) * LD + (Q - qa)];
     };
     double sq = 0.0;
+    T sqt = 0;
     // ---- far field: one Y sample per pixel.  Pixels of the near band (first PBy rows / PBx columns, where LR
     // row/column 0 is edge-replicated into the pad and frames subtract different Y samples) are left to
     // k_fwd_near; this kernel only publishes the Y rows/columns they read (Yb).
@@ -337,11 +338,11 @@ __global__ void __launch_bounds__(256)
         T g = 0;
         if (C > (T)0) {
             g = Mv[j] - C * Y(P, Q);
-            sq += (double)g * (double)g / (double)C;
+            sqt += g * g / C;  // C is a small integer count; summed per thread in T, per block in float64
         }
         G[((size_t)b * Hg + pg) * Wg + qg] = g;
     }
-    sq = wave_sum(sq);
+    sq = wave_sum(sq + (double)sqt);
     if (lane == 0)
         part[wave] = sq;
     __syncthreads();
@@ -382,10 +383,10 @@ __global__ void __launch_bounds__(256)
             hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
     if (ZERO) {
         // c'[p, q] = G[p+1, q+1]
-        fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)(pa + 1) * Wg + qa + 1, Wg, nr, nc, wave, lane);
+        fused::load_region<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src + (size_t)(pa + 1) * Wg + qa + 1, Wg, nr, nc, wave, lane);
         __syncthreads();
     } else {
-        fused::load_region<T, BR + 3, BR + 3>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
+        fused::load_region<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
         __syncthreads();
         constexpr int RW = TileCfg<T>::R;
         fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid);
