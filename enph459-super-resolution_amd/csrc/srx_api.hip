@@ -286,6 +286,8 @@ static bool basic_ibp_args_ok(const void *lr, int B, int N, int h, int w, const 
            kw > 0 && n_iter >= 0;
 }
 
+#define SRX_MAX_BATCH_PER_LAUNCH 32768  // gridDim.z <= 65535; larger batches go through in chunks of this many items
+
 template <typename T>
 static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
                         const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
@@ -293,8 +295,17 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
 {
     if (!basic_ibp_args_ok(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, hr))
         return SRX_E_INVALID;
-    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || B > 65535)
+    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS)
         return SRX_E_UNSUPPORTED;
+    if (B > SRX_MAX_BATCH_PER_LAUNCH) {  // the workspace is sized for one chunk and reused (stream order)
+        for (int b0 = 0; b0 < B; b0 += SRX_MAX_BATCH_PER_LAUNCH) {
+            const int bc = B - b0 < SRX_MAX_BATCH_PER_LAUNCH ? B - b0 : SRX_MAX_BATCH_PER_LAUNCH;
+            SRX_TRY(ibp_dispatch<T>(lr + (size_t)b0 * N * h * w, bc, N, h, w, sh, k, kh, kw, hr_init + (size_t)b0 * H * W, H, W,
+                                    f, n_iter, step, hr + (size_t)b0 * H * W, errors ? errors + (size_t)b0 * n_iter : nullptr,
+                                    ws, wsb, st, flags));
+        }
+        return SRX_OK;
+    }
     const bool can_fuse = fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f);
     if ((flags & SRX_FLAG_FUSED) && !can_fuse)
         return SRX_E_UNSUPPORTED;
@@ -316,8 +327,17 @@ static int saa_dispatch(const T *lr, int B, int N, int h, int w, const double *s
 {
     if (!lr || !sh || !out || B <= 0 || N <= 0 || h <= 0 || w <= 0 || f <= 0)
         return SRX_E_INVALID;
-    if (N > SRX_MAX_FRAMES || B > 65535)
+    if (N > SRX_MAX_FRAMES)
         return SRX_E_UNSUPPORTED;
+    if ((long)B * N > SRX_MAX_BATCH_PER_LAUNCH) {
+        const int step_b = SRX_MAX_BATCH_PER_LAUNCH / N > 0 ? SRX_MAX_BATCH_PER_LAUNCH / N : 1;
+        for (int b0 = 0; b0 < B; b0 += step_b) {
+            const int bc = B - b0 < step_b ? B - b0 : step_b;
+            SRX_TRY(saa_dispatch<T>(lr + (size_t)b0 * N * h * w, bc, N, h, w, sh, f, out + (size_t)b0 * h * f * w * f, ws, wsb,
+                                    st, flags));
+        }
+        return SRX_OK;
+    }
     const bool can_fuse = fused::saa_eligible(N, h, w, sh, f);
     if ((flags & SRX_FLAG_FUSED) && !can_fuse)
         return SRX_E_UNSUPPORTED;
@@ -392,6 +412,8 @@ size_t srx_backproject_workspace_bytes(int eb, int B, int H, int W) { return bac
 
 size_t srx_saa_workspace_bytes(int eb, int B, int N, int h, int w, int f)
 {
+    if ((long)B * N > SRX_MAX_BATCH_PER_LAUNCH)
+        B = SRX_MAX_BATCH_PER_LAUNCH / N > 0 ? SRX_MAX_BATCH_PER_LAUNCH / N : 1;
     size_t a = saa_ws_composed(eb, B, N, h, w, f), b = fused::saa_ws(eb, B, N, h, w, f);
     const size_t c = mosaic::saa_ws(eb, B, N, h, w, f);
     a = a > b ? a : b;
@@ -400,6 +422,8 @@ size_t srx_saa_workspace_bytes(int eb, int B, int N, int h, int w, int f)
 
 size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W, int f, unsigned flags)
 {
+    if (B > SRX_MAX_BATCH_PER_LAUNCH)
+        B = SRX_MAX_BATCH_PER_LAUNCH;
     size_t a = ibp_ws_composed(eb, B, N, h, w, H, W, f), b = fused::ibp_ws(eb, B, N, h, w, H, W, f);
     const size_t c = mosaic::ibp_ws(eb, B, N, H, W);
     b = b > c ? b : c;

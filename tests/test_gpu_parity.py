@@ -266,3 +266,32 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "fused"
     close(hr_p[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     np.testing.assert_allclose(errs_p[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
+
+
+def test_tiny_and_odd_inputs(prec):
+    """Shapes below the fused paths' minimum (composed path), a 1-pixel-wide frame, N = 1, n_iter = 0."""
+    from oracle import sr_oracle as O
+    rng = np.random.default_rng(21)
+    psf = synth.asymmetric_psf()
+    for (h, w, f, shifts) in [(6, 7, 2, synth.NOMINAL_4), (5, 1, 2, [(0.25, 0.0), (-0.25, 0.0)]), (9, 8, 3, [(0.1, 0.2)])]:
+        lr = np.rint(rng.uniform(0, 255, (len(shifts), h, w)))
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 4, 0.5)
+        saa = S.shift_and_add(list(lr), shifts, f)
+        close(saa, saa_o, PRIM_TOL[prec])
+        hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 4, 0.5, verbose=False)
+        close(hr, hr_o, IBP_TOL[prec])
+        np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
+        hr0, errs0 = S.ibp(list(lr), shifts, psf, saa_o, f, 0, 0.5, verbose=False)  # n_iter = 0: hr_init copy, no errors
+        assert np.array_equal(hr0, saa_o if prec == "f64" else saa_o.astype(np.float32).astype(np.float64)) and errs0 == []
+
+
+def test_unsupported_configurations_are_reported():
+    from sr_mi355x import _lib
+    lr = np.zeros((33, 8, 8))
+    with pytest.raises(_lib.SrxError) as ei:  # N = 33 > SRX_MAX_FRAMES
+        S.shift_and_add(list(lr), [(0.0, 0.0)] * 33, 2)
+    assert ei.value.status == _lib.E_UNSUPPORTED
+    with pytest.raises(_lib.SrxError):        # fused path demanded for a ragged shape
+        S.ibp_batched(np.zeros((1, 2, 8, 8)), [(0, 0), (0.5, 0.5)], synth.gaussian_psf(), np.zeros((1, 17, 16)), 2, 1, 0.5,
+                      flags=S.FLAG_FUSED)
