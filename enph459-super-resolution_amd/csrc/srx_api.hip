@@ -434,6 +434,17 @@ size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W,
     return a > b ? a : b;
 }
 
+int srx_interleave4_u8(const uint8_t *frames, int B, int h, int w, uint8_t *out, srx_stream_t s)
+{
+    if (!frames || !out || B <= 0 || h <= 0 || w <= 0)
+        return SRX_E_INVALID;
+    if (B > 65535)
+        return SRX_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_interleave4_u8, dim3(cdiv(2 * w, 64), cdiv(2 * h, 4), B), dim3(64, 4), 0, hs(s), frames, h, w, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
 #define SRX_DEFINE(SFX, T)                                                                                             \
     int srx_blur_##SFX(const T *img, int B, int H, int W, const double *k, int kh, int kw, T *out, srx_stream_t s)      \
     {                                                                                                                  \

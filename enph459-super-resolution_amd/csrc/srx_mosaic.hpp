@@ -615,6 +615,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     }
     constexpr int TS = TileCfg<T>::T_HR;
     const int dbg = getenv("SRX_DBG") ? atoi(getenv("SRX_DBG")) : 0;  // timing ablations only (results are wrong)
+    const size_t dbg_lds = getenv("SRX_DBG_LDS") ? (size_t)atoi(getenv("SRX_DBG_LDS")) : 0;  // extra LDS: caps blocks per CU
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
     for (int it = 0; it < n_iter; it++) {
@@ -630,13 +631,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
             SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
                        (size_t)N * h * w, pad, (size_t)H * W, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
         } else {
-            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), dbg_lds, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
                        eo, n_iter, scale, dbg);
             SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
                        (size_t)N * h * w, Yb, (size_t)Hp * Wp, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
         }
 #define SRX_BWDM(Z_, S_)                                                                                             \
-    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, 0, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, dbg)
+    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, dbg)
         if (zero) {
             if (sep)
                 SRX_BWDM(true, true);

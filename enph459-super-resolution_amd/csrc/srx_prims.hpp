@@ -488,6 +488,37 @@ __global__ void __launch_bounds__(256) k_quantize_u8(const T *__restrict__ in, s
     }
 }
 
+// 4-frame pixel interleave of the vendor live view (opt_materials/software/XPR_Software.py:196-205, 388-410):
+// plane_k = zeros(2h, 2w) uint8; plane_k[::2, ::2] = frame_k; plane_k = warpAffine(plane_k, translate(tx_k, ty_k),
+// BORDER_REFLECT_101)  i.e.  plane_k[y][x] = src_k[r101(y - ty_k)][r101(x - tx_k)];  out = sum_k plane_k as uint8 (wraps).
+// (tx, ty) = (0,0), (0,+1), (-1,+1), (-1,0): a true depth-to-space of the four half-pixel-shifted frames.
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1)
+        return 0;
+    while (i < 0 || i >= n)
+        i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ void __launch_bounds__(256) k_interleave4_u8(const uint8_t *__restrict__ frames, int h, int w, uint8_t *__restrict__ out)
+{
+    const int H = 2 * h, W = 2 * w;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H)
+        return;
+    const int tx[4] = {0, 0, -1, -1}, ty[4] = {0, 1, 1, 0};
+    const uint8_t *f = frames + (size_t)blockIdx.z * 4 * h * w;
+    unsigned acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int yy = reflect101(y - ty[k], H), xx = reflect101(x - tx[k], W);
+        if (!(yy & 1) && !(xx & 1))
+            acc += f[((size_t)k * h + (yy >> 1)) * w + (xx >> 1)];
+    }
+    out[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = (uint8_t)acc;  // np.sum(..., dtype=uint8): modulo 256
+}
+
 // out = in (copy) / out += in / out /= d
 template <typename T> __global__ void __launch_bounds__(256) k_add(T *__restrict__ out, const T *__restrict__ in, size_t n)
 {

@@ -41,6 +41,7 @@ _PLAIN = {
     "srx_profile_kernel_count": (_I, []),
     "srx_profile_kernel_name": (_c.c_char_p, [_I]),
     "srx_profile_get": (_I, [_I, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
+    "srx_interleave4_u8": (_I, [_P, _I, _I, _I, _P, _P]),
     "srx_shift_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "srx_zoom_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "srx_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),

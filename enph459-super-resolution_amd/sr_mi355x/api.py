@@ -317,3 +317,21 @@ def make_gaussian_psf(size=7, sigma=1.0):
     y, x = np.mgrid[-hw:hw + 1, -hw:hw + 1].astype(np.float64)
     k = np.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
     return k / k.sum()
+
+
+def interleave4(frames_u8):
+    """The vendor live view's 4-frame pixel interleave (XPR_Software.py:388-410): uint8 [4, h, w] (or [B, 4, h, w])
+    -> uint8 [2h, 2w]; frame k lands on the HR lattice phase its half-pixel shift corresponds to."""
+    t = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames_u8))
+    was_np = not isinstance(frames_u8, torch.Tensor)
+    t = t.to(device=_device(), dtype=torch.uint8).contiguous()
+    single = t.dim() == 3
+    if single:
+        t = t[None]
+    B, four, h, w = t.shape
+    if four != 4:
+        raise ValueError("interleave4 needs exactly 4 frames")
+    out = torch.empty((B, 2 * h, 2 * w), dtype=torch.uint8, device=t.device)
+    _lib.check(_lib.load().srx_interleave4_u8(_p(t), B, h, w, _p(out), _stream()), "srx_interleave4_u8")
+    out = out[0] if single else out
+    return out.cpu().numpy() if was_np else out

@@ -295,3 +295,23 @@ def test_unsupported_configurations_are_reported():
     with pytest.raises(_lib.SrxError):        # fused path demanded for a ragged shape
         S.ibp_batched(np.zeros((1, 2, 8, 8)), [(0, 0), (0.5, 0.5)], synth.gaussian_psf(), np.zeros((1, 17, 16)), 2, 1, 0.5,
                       flags=S.FLAG_FUSED)
+
+
+def test_interleave4_depth_to_space():
+    """Vendor live-view interleave (XPR_Software.py:388-410): bit-exact vs the numpy restatement, and in the interior
+    the pure PixelShuffle index map out[2i + py_k, 2j + px_k] = frame_k[i, j]."""
+    from oracle import sr_oracle as O
+    rng = np.random.default_rng(8)
+    for (h, w) in [(5, 7), (32, 48), (1, 1)]:
+        fr = rng.integers(0, 256, (4, h, w), dtype=np.uint8)
+        out = S.interleave4(fr)
+        assert out.dtype == np.uint8 and out.shape == (2 * h, 2 * w)
+        assert np.array_equal(out, O.interleave4(fr))
+    fr = rng.integers(0, 256, (4, 16, 16), dtype=np.uint8)
+    out = S.interleave4(fr)
+    for k, (tx, ty) in enumerate([(0, 0), (0, 1), (-1, 1), (-1, 0)]):
+        # frame k's samples land on HR phase (ty mod 2, tx mod 2); away from the reflected border nothing else does
+        y = np.arange(2, 30)
+        yy, xx = np.meshgrid(y, y, indexing="ij")
+        m = ((yy - ty) % 2 == 0) & ((xx - tx) % 2 == 0)
+        assert np.array_equal(out[2:30, 2:30][m[:, :]], fr[k][((yy - ty) // 2)[m], ((xx - tx) // 2)[m]])

@@ -51,3 +51,16 @@ def test_discovery(tmp_path):
     assert [os.path.basename(p) for p in session.discover_sessions(str(tmp_path), "mono_barcodes")] == ["b"]
     assert session.detect_kind(str(tmp_path / "a")) == "mono_cal_target"
     assert session.detect_kind(str(tmp_path / "b")) is None
+
+
+def test_oracle_interleave4_is_a_pixel_shuffle():
+    """The numpy restatement of the vendor interleave: interior = depth-to-space of the four frames."""
+    from oracle import sr_oracle as O
+    rng = np.random.default_rng(2)
+    fr = rng.integers(0, 256, (4, 12, 10), dtype=np.uint8)
+    out = O.interleave4(fr)
+    assert out.shape == (24, 20) and out.dtype == np.uint8
+    assert np.array_equal(out[0::2, 0::2], fr[0])                    # (tx, ty) = (0, 0)
+    assert np.array_equal(out[3::2, 0::2], fr[1][1:])                # (0, +1): rows 2i+1
+    assert np.array_equal(out[3::2, 1:-1:2], fr[2][1:, 1:])          # (-1, +1): rows 2i+1, columns 2j-1
+    assert np.array_equal(out[0::2, 1:-1:2], fr[3][:, 1:])           # (-1, 0)
