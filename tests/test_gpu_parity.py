@@ -315,3 +315,72 @@ def test_interleave4_depth_to_space():
         yy, xx = np.meshgrid(y, y, indexing="ij")
         m = ((yy - ty) % 2 == 0) & ((xx - tx) % 2 == 0)
         assert np.array_equal(out[2:30, 2:30][m[:, :]], fr[k][((yy - ty) // 2)[m], ((xx - tx) // 2)[m]])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Full-size properties (BASELINE.json sizes, too large for the CPU oracle): size-independent invariants
+# ---------------------------------------------------------------------------------------------------------
+def _full_c2_batch(B):
+    """B patches of the headline workload: 64x64 LR, f=4, N=16 phases, frames from the product's own forward model."""
+    f, shifts, psf = 4, synth.phase_shifts(4), synth.gaussian_psf()
+    truths = np.stack([synth.truth_image(256, 256, seed=4000 + i) for i in range(8)])
+    x = torch.from_numpy(truths).cuda().float().repeat((B + 7) // 8, 1, 1)[:B].contiguous()
+    x = x + torch.arange(B, device="cuda", dtype=torch.float32)[:, None, None] * 0.01  # make every item distinct
+    lr = torch.stack([S.forward_model_batched(x, psf, s, f, precision="f32") for s in shifts], dim=1).contiguous()
+    return f, shifts, psf, x, lr
+
+
+def test_full_size_ibp_fixed_point():
+    """Noise-free frames of x: every residual is zero, so IBP started at x must stay at x and report MSE ~ 0
+    (headline batch, B = 1024 patches of 256x256; and one 3072x4096 mono_cal_target-shaped frame)."""
+    S.set_precision("f32")
+    f, shifts, psf, x, lr = _full_c2_batch(1024)
+    hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
+    assert S.last_path() == "mosaic"
+    assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
+    # the reference's largest shape: N = 5 nominal shifts, f = 2, 1536x2048 -> 3072x4096, one item
+    f2, sh5, psf_a = 2, synth.NOMINAL_5, synth.asymmetric_psf()
+    big = torch.from_numpy(synth.truth_image(384, 512, seed=5)).cuda().float().repeat(8, 8)[None].contiguous()
+    assert big.shape == (1, 3072, 4096)
+    lr5 = torch.stack([S.forward_model_batched(big, psf_a, s, f2) for s in sh5], dim=1).contiguous()
+    hr5, e5 = S.ibp_batched(lr5, sh5, psf_a, big, f2, 2, 0.5)
+    assert float((hr5 - big).abs().max()) < 2e-3 and float(e5.max()) < 1e-6
+
+
+def test_full_size_paths_agree_and_items_are_independent():
+    """Headline patch size, noisy frames: the mosaic path, the per-frame fused path and (on a few items) the composed
+    path give the same result; an item's result does not depend on its batch."""
+    S.set_precision("f32")
+    f, shifts, psf, x, lr = _full_c2_batch(96)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    lr = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255)
+    saa = S.shift_and_add_batched(lr, shifts, f)
+    assert S.last_path() == "mosaic"
+    saa_p = S.shift_and_add_batched(lr, shifts, f, flags=S.FLAG_PER_FRAME)
+    assert float((saa - saa_p).abs().max()) < 2e-3
+    hr_m, e_m = S.ibp_batched(lr, shifts, psf, saa, f, 8, 0.5)
+    assert S.last_path() == "mosaic"
+    hr_p, e_p = S.ibp_batched(lr, shifts, psf, saa, f, 8, 0.5, flags=S.FLAG_PER_FRAME)
+    assert S.last_path() == "fused"
+    assert float((hr_m - hr_p).abs().max()) < 5e-3
+    np.testing.assert_allclose(e_m.cpu().numpy(), e_p.cpu().numpy(), rtol=2e-5)
+    hr_c, e_c = S.ibp_batched(lr[:3], shifts, psf, saa[:3], f, 8, 0.5, flags=S.FLAG_COMPOSED)
+    assert float((hr_m[:3] - hr_c).abs().max()) < 5e-3
+    one, e1 = S.ibp_batched(lr[41:42], shifts, psf, saa[41:42], f, 8, 0.5)
+    assert torch.equal(one[0], hr_m[41])
+
+
+def test_full_size_linearity():
+    """blur, forward_model and back_project are linear maps: f(a x + b y) = a f(x) + b f(y) at the headline size."""
+    S.set_precision("f32")
+    rng = torch.Generator(device="cuda")
+    rng.manual_seed(9)
+    x = torch.rand((64, 256, 256), generator=rng, device="cuda") * 255
+    y = torch.rand((64, 256, 256), generator=rng, device="cuda") * 255
+    psf, s = synth.asymmetric_psf(), (0.375, -0.125)
+    for fn in (lambda t: S.blur_batched(t, psf), lambda t: S.forward_model_batched(t, psf, s, 4),
+               lambda t: S.back_project_batched(S.forward_model_batched(t, psf, s, 4), psf, s, 4, (256, 256))):
+        lhs = fn(0.25 * x + 0.5 * y)
+        rhs = 0.25 * fn(x) + 0.5 * fn(y)
+        assert float((lhs - rhs).abs().max()) < 2e-3
