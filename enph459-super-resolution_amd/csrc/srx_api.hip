@@ -360,6 +360,18 @@ extern "C" {
 
 int srx_version(void) { return 100; }
 
+#ifdef SRX_STAMPS
+// diagnostic build only: copy the phase stamps of the mosaic kernels to the host and clear them
+int srx_debug_stamps(unsigned long long *host_out)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return SRX_E_HIP;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(srx::mosaic::srx_dbg_stamps), sizeof(unsigned long long) * 2 * 8 * 40000) != hipSuccess)
+        return SRX_E_HIP;
+    return SRX_OK;
+}
+#endif
+
 const char *srx_strerror(int s)
 {
     switch (s) {

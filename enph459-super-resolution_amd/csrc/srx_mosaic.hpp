@@ -29,6 +29,24 @@
 namespace srx {
 namespace mosaic {
 
+// Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
+// buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
+#ifdef SRX_STAMPS
+__device__ unsigned long long srx_dbg_stamps[2][8][40000];  // [kernel][phase][block]
+#define SRX_STAMP(K, PH)                                                                                       \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && threadIdx.y == 0) {                                                             \
+            unsigned long long _t;                                                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
+            const unsigned _blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+            if (_blk < 40000)                                                                                    \
+                srx_dbg_stamps[K][PH][_blk] = _t;                                                                \
+        }                                                                                                       \
+    } while (0)
+#else
+#define SRX_STAMP(K, PH) do { } while (0)
+#endif
+
 using fused::corr7_strip8;
 using fused::Kernel7;
 using fused::TileCfg;
@@ -297,6 +315,7 @@ __global__ void __launch_bounds__(256)
         Cv[j] = Cg[gi];
         Mv[j] = Mg[(size_t)b * Hg * Wg + gi];
     }
+    SRX_STAMP(0, 0);
     int pa = 0, qa = 0;
     if (!ZERO) {
         pa = max(0, p0 - ma.Dy - R);
@@ -306,12 +325,15 @@ __global__ void __launch_bounds__(256)
         if (nr > 3 && nc > 3) {
             fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? 12 : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
+            SRX_STAMP(0, 1);
             fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid);
+            SRX_STAMP(0, 2);
             // rows of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS)
             const int r_lo = max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
             fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc, qa == 0, ma.wfx, tid);
         }
         __syncthreads();
+        SRX_STAMP(0, 3);
     }
     auto Y = [&](int P, int Q) -> T {
         return ZERO ? src[(size_t)min(max(P + 1 - SRX_NPAD, 0), H - 1) * W + min(max(Q + 1 - SRX_NPAD, 0), W - 1)]
@@ -342,6 +364,7 @@ __global__ void __launch_bounds__(256)
         }
         G[((size_t)b * Hg + pg) * Wg + qg] = g;
     }
+    SRX_STAMP(0, 4);
     sq = wave_sum(sq + (double)sqt);
     if (lane == 0)
         part[wave] = sq;
@@ -351,6 +374,7 @@ __global__ void __launch_bounds__(256)
         if (s != 0.0)
             atomicAdd(&errors[(size_t)b * errors_stride], s * scale);
     }
+    SRX_STAMP(0, 5);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -374,6 +398,7 @@ __global__ void __launch_bounds__(256)
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
     const int nr = pb - pa, nc = qb - qa;
+    SRX_STAMP(1, 0);
     // this thread's TS*TS/256 hr pixels, fetched up front (clamped addresses): latency hides behind the tile work
     T hv[TS / 32][8];
 #pragma unroll
@@ -388,24 +413,39 @@ __global__ void __launch_bounds__(256)
     } else {
         fused::load_region<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
         __syncthreads();
+        SRX_STAMP(1, 1);
         constexpr int RW = TileCfg<T>::R;
         fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid);
+        SRX_STAMP(1, 2);
         const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
         fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid);
+        SRX_STAMP(1, 3);
     }
-    // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad
-    if (r0 < 3 || c0 < 3 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
-        for (int rr = wave; rr < nr; rr += 4) {
-            const int p = pa + rr;
-            const bool rout = p < SRX_NPAD || p >= H + SRX_NPAD;
-            for (int cc = lane; cc < nc; cc += 64) {
-                const int q = qa + cc;
-                if (rout || q < SRX_NPAD || q >= W + SRX_NPAD)
-                    reg[rr * LD + cc] = 0;
-            }
+    // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad.  Of the window
+    // [r0-3, r0+TS+3) x [c0-3, c0+TS+3) only the three rows/columns just outside an image edge are ever read by
+    // a pixel this tile writes: 12 strips of TS+6 cells.
+    if (r0 == 0 || c0 == 0 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
+        constexpr int WN = TS + 6;
+        T *win0 = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
+        const int wrb = H - r0 + 3, wcb = W - c0 + 3;         // window row / column of image row H / column W
+        for (int idx = tid; idx < 12 * WN; idx += 256) {
+            const int strip = idx / WN, pos = idx - strip * WN, o = strip % 3;
+            int wr, wc;
+            bool on;
+            if (strip < 3)
+                wr = o, wc = pos, on = r0 == 0;
+            else if (strip < 6)
+                wr = wrb + o, wc = pos, on = wr < WN;
+            else if (strip < 9)
+                wr = pos, wc = o, on = c0 == 0;
+            else
+                wr = pos, wc = wcb + o, on = wc < WN;
+            if (on)
+                win0[wr * LD + wc] = 0;
         }
         __syncthreads();
     }
+    SRX_STAMP(1, 4);
     const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
     const int c = c0 + lane;
     const size_t base = (size_t)b * H * W;
@@ -425,6 +465,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    SRX_STAMP(1, 5);
 }
 
 // ---------------------------------------------------------------------------------------

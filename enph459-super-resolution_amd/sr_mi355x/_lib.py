@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsrx.so")
+SO_PATH = os.environ.get("SRX_LIB", os.path.join(_HERE, "libsrx.so"))  # SRX_LIB: diagnostic builds only
 _lib = None
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of the mosaic tile kernels from a DIAGNOSTIC build (hipcc -DSRX_STAMPS -> libsrx_stamps.so):
+s_memtime stamps by thread 0 of every block at phase boundaries.  Read the shares, not the kernel's run time.
+    SRX_LIB=.../libsrx_stamps.so python tools/stamps.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enph459-super-resolution_amd"))
+import torch  # noqa: E402
+import sr_mi355x as S  # noqa: E402
+from sr_mi355x import _lib, synth  # noqa: E402
+
+f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), 1024
+lr = torch.rand((B, 16, 64, 64), device="cuda") * 255
+saa = S.shift_and_add_batched(lr, shifts, f)
+S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
+buf = np.zeros((2, 8, 40000), dtype=np.uint64)
+lib = _lib.load()
+lib.srx_debug_stamps.argtypes = [ctypes.c_void_p]
+assert lib.srx_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+names = {0: ("k_fwd_mosaic", ["prefetch M,C", "load region + store", "column pass", "row pass", "pixel phase", "reduce+atomic"]),
+         1: ("k_bwd_mosaic", ["prefetch hr", "load region + store", "column pass", "row pass", "zero border", "blur+update"])}
+for k, (kn, ph) in names.items():
+    t = buf[k].astype(np.int64)
+    nb = 25600 if k == 0 else 16384
+    ok = (t[0, :nb] > 0) & (t[5, :nb] > t[0, :nb])
+    tot = (t[5, :nb] - t[0, :nb])[ok]
+    print(f"{kn}: blocks {ok.sum()}, median cycles/block {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f})")
+    for i in range(5):
+        d = (t[i + 1, :nb] - t[i, :nb])[ok]
+        print(f"    {ph[i + 1]:22s} median {np.median(d):8.0f}  share {100 * np.median(d) / np.median(tot):5.1f} %")
