@@ -600,7 +600,7 @@ __device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, 
 }
 
 template <typename T, int S, int MODE>
-__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w)
+__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w, int need_lo = 0)
 {
     const T z = pole<T>();
     const int n = MODE == 1 ? n_in - 3 : n_in;
@@ -613,7 +613,7 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
     st.a1 = st.next, st.a2 = 0, st.a3 = 0;
     if (MODE != 2)
         line[(n - 1) * S] = st.next;
-    anticausal_run<T, S, MODE>(line, n - 2, 0, st, w0, w1, w2, w3);
+    anticausal_run<T, S, MODE>(line, n - 2, need_lo, st, w0, w1, w2, w3);
 }
 
 // The same pass over `nlines` (<= 128) lines with TWO threads per line (256-thread block, barriers inside): thread
@@ -623,7 +623,7 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
 // chain, which is what bounds this phase (2 of a block's 4 waves used to walk, 2 idled at the barrier).
 template <typename T, int S, int MODE, int R>
 __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pitch, int nlines, int n_in, bool edge,
-                                               const T *__restrict__ w, int tid)
+                                               const T *__restrict__ w, int tid, int need_lo = 0)
 {
     constexpr int O = MODE == 1 ? 3 : 0;
     const T z = pole<T>(), zfin = z / (z - (T)1);
@@ -634,11 +634,16 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     T *line = base + (active ? lineid : 0) * line_pitch;
     if (n < 4 * R + 16) {  // too short to split (block-uniform): one thread per line
         if (active && seg == 0)
-            walk_line<T, S, MODE>(line, n_in, edge, w);
+            walk_line<T, S, MODE>(line, n_in, edge, w, need_lo);
         __syncthreads();
         return;
     }
-    const int mid = (n / 2) & ~7;
+    // Outputs below need_lo (block-uniform) are read by nobody: the first half's anticausal recursion stops there.
+    // The cut balances the two halves' instruction counts (x2: plain step 5, step with the FIR 13, warm-up step 4):
+    //   first : causal [0, mid) + R warm-up + anticausal [need_lo, mid);   second: R warm-up + causal and anticausal [mid, n)
+    constexpr int WC = MODE == 1 ? 13 : 5, WA = MODE == 2 ? 13 : 5, WW = MODE == 1 ? 13 : 4;
+    int mid = (((WW - 4) * R + (WC + WA) * n + WA * need_lo) / (2 * (WC + WA)) + 4) & ~7;
+    mid = min(max(mid, (R + 7) & ~7), (n - R) & ~7);
     WalkState<T> st;
     st.g0 = st.g1 = st.g2 = 0;
     T pre[R + 3];
@@ -720,7 +725,7 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
                 st.next = z * (st.next - pre[j]);
                 st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
             }
-            anticausal_run<T, S, MODE>(line, mid - 1, 0, st, w0, w1, w2, w3);
+            anticausal_run<T, S, MODE>(line, mid - 1, need_lo, st, w0, w1, w2, w3);
         }
     }
     __syncthreads();

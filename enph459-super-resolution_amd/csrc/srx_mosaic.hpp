@@ -289,6 +289,11 @@ __global__ void __launch_bounds__(256)
 //   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
 //   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
 // ---------------------------------------------------------------------------------------
+// 1 / C for a count C (a small non-negative integer stored as T): 0 where C == 0.  float: v_rcp_f32 (1 ulp;
+// the MSE trace is a float64 sum of ~1e7 such terms, compared to 1e-6 relative); double: the exact quotient.
+__device__ __forceinline__ float rcp_count(float c) { return c > 0.f ? __builtin_amdgcn_rcpf(c) : 0.f; }
+__device__ __forceinline__ double rcp_count(double c) { return c > 0.0 ? 1.0 / c : 0.0; }
+
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
     k_fwd_mosaic(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
@@ -326,11 +331,12 @@ __global__ void __launch_bounds__(256)
             fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? 12 : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
             SRX_STAMP(0, 1);
-            fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid);
-            SRX_STAMP(0, 2);
-            // rows of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS)
+            // rows / columns of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS) x [q0 - Dx, q0 - Dx + TS)
             const int r_lo = max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
-            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc, qa == 0, ma.wfx, tid);
+            fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid, r_lo);
+            SRX_STAMP(0, 2);
+            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc, qa == 0, ma.wfx, tid,
+                                              max(0, q0 - ma.Dx - qa));
         }
         __syncthreads();
         SRX_STAMP(0, 3);
@@ -344,25 +350,43 @@ __global__ void __launch_bounds__(256)
     // ---- far field: one Y sample per pixel.  Pixels of the near band (first PBy rows / PBx columns, where LR
     // row/column 0 is edge-replicated into the pad and frames subtract different Y samples) are left to
     // k_fwd_near; this kernel only publishes the Y rows/columns they read (Yb).
+    // Thread (prow + j * RPJ, pcol) of the tile; everything that does not depend on j is hoisted by hand and the
+    // indices stay 32-bit (a batch chunk is < 2^31 elements): the unrolled pixel phase used to be ~45 % of this
+    // kernel's VALU instructions, most of them 64-bit index arithmetic, predicates and the IEEE division.
+    constexpr int RPJ = 256 / TS;
+    const int prow = tid / TS, pcol = tid % TS;
+    const int qg = q0 + pcol, Q = qg - ma.Dx;
+    const bool qok = qg < Wg && !(dbg & 8), qfar = qg >= ma.PBx;
+    const bool qpub = !ZERO && Q >= 0 && Q <= Wp - 4, qlow = Q < ma.YBx;
+    T *Gp = G + (size_t)b * Hg * Wg + qg;
+    T *Yp = Yb + (size_t)b * Hp * Wp + Q;
+    const bool fast = p0 >= ma.PBy && q0 >= ma.PBx && p0 + TS <= Hg && q0 + TS <= Wg &&
+                      (ZERO || (p0 - ma.Dy >= ma.YBy && q0 - ma.Dx >= ma.YBx)) && !(dbg & 8);  // block-uniform
+    if (fast) {
+        // interior tile: every pixel is far field and inside the plane, nothing to publish
 #pragma unroll
-    for (int j = 0; j < NPX; j++) {
-        const int idx = tid + 256 * j;
-        const int pg = p0 + idx / TS, qg = q0 + idx % TS;  // TS is a power of two
-        if (pg >= Hg || qg >= Wg || (dbg & 8))
-            continue;
-        const int P = pg - ma.Dy, Q = qg - ma.Dx;
-        const bool far = pg >= ma.PBy && qg >= ma.PBx;
-        if (!ZERO && P >= 0 && Q >= 0 && P <= Hp - 4 && Q <= Wp - 4 && (P < ma.YBy || Q < ma.YBx))
-            Yb[((size_t)b * Hp + P) * Wp + Q] = Y(P, Q);
-        if (!far)
-            continue;
-        const T C = Cv[j];
-        T g = 0;
-        if (C > (T)0) {
-            g = Mv[j] - C * Y(P, Q);
-            sqt += g * g / C;  // C is a small integer count; summed per thread in T, per block in float64
+        for (int j = 0; j < NPX; j++) {
+            const int pg = p0 + prow + j * RPJ;
+            const T C = Cv[j];
+            const T g = C > (T)0 ? Mv[j] - C * Y(pg - ma.Dy, Q) : (T)0;
+            sqt += g * g * rcp_count(C);
+            Gp[pg * Wg] = g;
         }
-        G[((size_t)b * Hg + pg) * Wg + qg] = g;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const int pg = p0 + prow + j * RPJ, P = pg - ma.Dy;
+            if (pg >= Hg || !qok)
+                continue;
+            if (qpub && P >= 0 && P <= Hp - 4 && (qlow || P < ma.YBy))
+                Yp[P * Wp] = Y(P, Q);
+            if (!(qfar && pg >= ma.PBy))
+                continue;
+            const T C = Cv[j];
+            const T g = C > (T)0 ? Mv[j] - C * Y(P, Q) : (T)0;
+            sqt += g * g * rcp_count(C);
+            Gp[pg * Wg] = g;
+        }
     }
     SRX_STAMP(0, 4);
     sq = wave_sum(sq + (double)sqt);
@@ -415,10 +439,10 @@ __global__ void __launch_bounds__(256)
         __syncthreads();
         SRX_STAMP(1, 1);
         constexpr int RW = TileCfg<T>::R;
-        fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid);
-        SRX_STAMP(1, 2);
         const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
-        fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid);
+        fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid, r_lo);
+        SRX_STAMP(1, 2);
+        fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid, c0 + 9 - qa);
         SRX_STAMP(1, 3);
     }
     // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad.  Of the window
@@ -565,9 +589,9 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid);
     const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
-    fused::walk_pass_2seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid);
+    fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid, r_lo);
+    fused::walk_pass_2seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid, c0 + SRX_NPAD - qa);
     for (int idx = tid; idx < TS * TS; idx += 256) {
         const int r = r0 + idx / TS, c = c0 + idx % TS;
         if (r < H && c < W)
