@@ -289,10 +289,10 @@ __global__ void __launch_bounds__(256)
 //   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
 //   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
 // ---------------------------------------------------------------------------------------
-// 1 / C for a count C (a small non-negative integer stored as T): 0 where C == 0.  float: v_rcp_f32 (1 ulp;
+// 1 / max(C, 1) for a count C (a small non-negative integer stored as T; the numerator is 0 where C == 0).  float: v_rcp_f32 (1 ulp;
 // the MSE trace is a float64 sum of ~1e7 such terms, compared to 1e-6 relative); double: the exact quotient.
-__device__ __forceinline__ float rcp_count(float c) { return c > 0.f ? __builtin_amdgcn_rcpf(c) : 0.f; }
-__device__ __forceinline__ double rcp_count(double c) { return c > 0.0 ? 1.0 / c : 0.0; }
+__device__ __forceinline__ float rcp_count(float c) { return __builtin_amdgcn_rcpf(fmaxf(c, 1.f)); }
+__device__ __forceinline__ double rcp_count(double c) { return 1.0 / fmax(c, 1.0); }
 
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
@@ -362,14 +362,21 @@ __global__ void __launch_bounds__(256)
     T *Yp = Yb + (size_t)b * Hp * Wp + Q;
     const bool fast = p0 >= ma.PBy && q0 >= ma.PBx && p0 + TS <= Hg && q0 + TS <= Wg &&
                       (ZERO || (p0 - ma.Dy >= ma.YBy && q0 - ma.Dx >= ma.YBx)) && !(dbg & 8);  // block-uniform
+    // all of this thread's Y samples first, unconditionally (clamped into the region: values of pixels that are
+    // not stored are never used), so that the LDS reads are one batch instead of one round trip per pixel
+    T Yv[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int P = p0 + prow + j * RPJ - ma.Dy;
+        Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
+    }
     if (fast) {
         // interior tile: every pixel is far field and inside the plane, nothing to publish
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             const int pg = p0 + prow + j * RPJ;
-            const T C = Cv[j];
-            const T g = C > (T)0 ? Mv[j] - C * Y(pg - ma.Dy, Q) : (T)0;
-            sqt += g * g * rcp_count(C);
+            const T g = Cv[j] > (T)0 ? Mv[j] - Cv[j] * Yv[j] : (T)0;  // Yv may be LDS garbage where C = 0
+            sqt += g * g * rcp_count(Cv[j]);
             Gp[pg * Wg] = g;
         }
     } else {
@@ -379,12 +386,11 @@ __global__ void __launch_bounds__(256)
             if (pg >= Hg || !qok)
                 continue;
             if (qpub && P >= 0 && P <= Hp - 4 && (qlow || P < ma.YBy))
-                Yp[P * Wp] = Y(P, Q);
+                Yp[P * Wp] = Yv[j];
             if (!(qfar && pg >= ma.PBy))
                 continue;
-            const T C = Cv[j];
-            const T g = C > (T)0 ? Mv[j] - C * Y(P, Q) : (T)0;
-            sqt += g * g * rcp_count(C);
+            const T g = Cv[j] > (T)0 ? Mv[j] - Cv[j] * Yv[j] : (T)0;  // Yv may be LDS garbage where C = 0
+            sqt += g * g * rcp_count(Cv[j]);
             Gp[pg * Wg] = g;
         }
     }
