@@ -64,7 +64,6 @@ enum KernelId {
     KID_BWD_TILE,
     KID_MOSAIC_BUILD,
     KID_FWD_MOSAIC,
-    KID_FWD_NEAR,
     KID_BWD_MOSAIC,
     KID_SAA_TILE,
     KID_COUNT

@@ -64,7 +64,6 @@ struct AxisDev {  // kernel-argument part of a plan
 
 template <typename T> struct MosaicArgs {
     int Dy, Dx, PBy, PBx;  // G coordinates p' < PB form the near band (edge-replicated LR row/column 0)
-    int YBy, YBx;          // Y rows < YBy / columns < YBx are what near-band pixels subtract
     T wfy[4], wfx[4];  // forward FIR (after the prefilter)
     T wby[4], wbx[4];  // backward FIR (before the prefilter)
 };
@@ -131,34 +130,47 @@ __global__ void __launch_bounds__(64) k_build_mtaps(MTap *__restrict__ tab, int 
     tab[(size_t)k * len + p] = t;
 }
 
-// M = sum of contributing LR samples, C = their count, V = sum over far-field pixels of the within-pixel
-// scatter sum_k (l_k - mean)^2 (constant over the iterations; only non-zero when C > 1 somewhere)
+// index of a near-band pixel (p < PBy or q < PBx) in the compact band arrays: the PBy full rows first, then the
+// PBx-wide strip of the rows below
+__device__ __forceinline__ int near_index(int p, int q, int Wg, int PBy, int PBx)
+{
+    return p < PBy ? p * Wg + q : PBy * Wg + (p - PBy) * PBx + q;
+}
+
+// M = sum of contributing LR samples, C = their count; on the near band also Mu = the sum over the samples that sit
+// at their own (unreplicated) position, the ones the MSE trace counts.  V = sum over pixels of the within-pixel
+// scatter sum_k (l_k - mean)^2 of the counted samples (constant over the iterations; non-zero only where two
+// frames share a phase)
 template <typename T>
 __global__ void __launch_bounds__(256)
     k_mosaic_build(const T *__restrict__ lr, int N, int h, int w, const MTap *__restrict__ tabY,
-                   const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, T *__restrict__ Mg,
-                   T *__restrict__ Cg, double *__restrict__ Vtot)
+                   const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
+                   T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot)
 {
     __shared__ double part[4];
     const int q = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
     double var = 0.0;
     if (p < Hg && q < Wg) {
-        double M = 0.0, S2 = 0.0;
-        int C = 0;
+        const bool nearpx = p < PBy || q < PBx;
+        double M = 0.0, S1 = 0.0, S2 = 0.0;  // S1, S2: over the counted samples
+        int C = 0, Cu = 0;
         for (int k = 0; k < N; k++) {
             const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
             if (ty.i >= 0 && tx.i >= 0) {
                 const double l = (double)lr[(((size_t)b * N + k) * h + ty.i) * w + tx.i];
                 M += l;
-                S2 += l * l;
                 C++;
+                if (ty.rho == p - Dy && tx.rho == q - Dx)
+                    S1 += l, S2 += l * l, Cu++;
             }
         }
         Mg[((size_t)b * Hg + p) * Wg + q] = (T)M;
         if (b == 0)
             Cg[(size_t)p * Wg + q] = (T)C;
-        if (C > 1 && p >= PBy && q >= PBx)
-            var = S2 - M * M / (double)C;
+        if (nearpx)
+            Mu[(size_t)b * NB + near_index(p, q, Wg, PBy, PBx)] = (T)S1;
+        if (Cu > 1)
+            var = S2 - S1 * S1 / (double)Cu;
     }
     var = wave_sum(var);
     if (threadIdx.x == 0)
@@ -180,14 +192,11 @@ __global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors
 }
 
 // ---------------------------------------------------------------------------------------
-// near band: per pixel, the compact list of frames that contribute there (built once per call)
+// near band (G coordinates p < PBy or q < PBx): LR row/column 0 of a frame is edge-replicated into the 12-px pad, so
+// a pixel there collects several frames and each subtracts its own Y sample.  Built once per call, shared by all
+// items: per pixel  ncu = cnt | Cu << 8  (frames landing there | of which at their own position) and the list of
+// Y coordinates they subtract, packed row | column << 16, in slots of NS = N rounded up to 4.
 // ---------------------------------------------------------------------------------------
-struct NEnt {
-    int off;   // offset of the LR sample inside one item's [N, h, w] stack
-    int yoff;  // offset of the Y sample it subtracts inside one item's Y source plane
-    int unc;   // 1 if this is the sample's own (unreplicated) position: counts for the MSE trace
-};
-
 __device__ __forceinline__ void near_px(int idx, int Wg, int PBy, int PBx, int &p, int &q)
 {
     if (idx < PBy * Wg) {
@@ -198,106 +207,43 @@ __device__ __forceinline__ void near_px(int idx, int Wg, int PBy, int PBx, int &
     }
 }
 
-// ZERO: the Y source is the plain blurred plane [H, W] (Y[P,Q] = b[clamp(P-11), clamp(Q-11)]); else the Yb plane [Hp, Wp]
 __global__ void __launch_bounds__(256)
-    k_build_near(const MTap *__restrict__ tabY, const MTap *__restrict__ tabX, int N, int h, int w, int Hg, int Wg, int PBy,
-                 int PBx, int Dy, int Dx, int zero, int H, int W, int NB, int *__restrict__ ncnt, NEnt *__restrict__ nent)
+    k_build_near(const MTap *__restrict__ tabY, const MTap *__restrict__ tabX, int N, int NS, int Hg, int Wg, int PBy, int PBx,
+                 int Dy, int Dx, int NB, int *__restrict__ ncu, int *__restrict__ nyx)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NB)
         return;
     int p, q;
     near_px(idx, Wg, PBy, PBx, p, q);
-    int cnt = 0;
+    int cnt = 0, cu = 0;
     for (int k = 0; k < N; k++) {
         const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
         if (ty.i >= 0 && tx.i >= 0) {
-            NEnt e;
-            e.off = (k * h + ty.i) * w + tx.i;
-            e.yoff = zero ? min(max(ty.rho + 1 - SRX_NPAD, 0), H - 1) * W + min(max(tx.rho + 1 - SRX_NPAD, 0), W - 1)
-                          : ty.rho * (W + 2 * SRX_NPAD) + tx.rho;
-            e.unc = (ty.rho == p - Dy && tx.rho == q - Dx) ? 1 : 0;
-            nent[(size_t)idx * N + cnt++] = e;
+            nyx[(size_t)idx * NS + cnt++] = ty.rho | (tx.rho << 16);
+            cu += (ty.rho == p - Dy && tx.rho == q - Dx) ? 1 : 0;
         }
     }
-    ncnt[idx] = cnt;
-}
-
-// G on the near band: the reference's sum, frame by frame, over the frames that land on each pixel.
-// One thread = one band pixel of NEAR_IB consecutive batch items: the pixel's entry list (shared by all
-// items) is read once per entry and its 2 * NEAR_IB operand loads are issued together.
-#define NEAR_IB 8
-template <typename T>
-__global__ void __launch_bounds__(256)
-    k_fwd_near(const T *__restrict__ lr, size_t lr_item, const T *__restrict__ ysrc, size_t y_item, int N, int B, int Hg,
-               int Wg, int PBy, int PBx, int NB, const int *__restrict__ ncnt, const NEnt *__restrict__ nent,
-               T *__restrict__ G, double *__restrict__ errors, int errors_stride, double scale)
-{
-    __shared__ double part[4][NEAR_IB];
-    int bx, by, bz;
-    xcd_block(bx, by, bz);  // the ~34 blocks of one item group share an XCD: replicated samples hit its L2
-    const int idx = bx * 256 + threadIdx.x, b0 = by * NEAR_IB;
-    double sq[NEAR_IB];
-    T g[NEAR_IB];
-#pragma unroll
-    for (int i = 0; i < NEAR_IB; i++)
-        sq[i] = 0.0, g[i] = 0;
-    if (idx < NB) {
-        const int cnt = ncnt[idx];
-        const NEnt *ent = nent + (size_t)idx * N;
-        for (int e = 0; e < cnt; e++) {
-            const NEnt en = ent[e];
-            T l[NEAR_IB], y[NEAR_IB];
-#pragma unroll
-            for (int i = 0; i < NEAR_IB; i++) {
-                const size_t b = min(b0 + i, B - 1);  // clamped duplicate for a ragged last group; dropped at the store
-                l[i] = lr[b * lr_item + en.off];
-                y[i] = ysrc[b * y_item + en.yoff];
-            }
-#pragma unroll
-            for (int i = 0; i < NEAR_IB; i++) {
-                const T d = l[i] - y[i];
-                g[i] += d;
-                if (en.unc)
-                    sq[i] += (double)d * (double)d;
-            }
-        }
-        int p, q;
-        near_px(idx, Wg, PBy, PBx, p, q);
-#pragma unroll
-        for (int i = 0; i < NEAR_IB; i++)
-            if (b0 + i < B)
-                G[((size_t)(b0 + i) * Hg + p) * Wg + q] = g[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NEAR_IB; i++) {
-        const double s = wave_sum(sq[i]);
-        if ((threadIdx.x & 63) == 0)
-            part[threadIdx.x >> 6][i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NEAR_IB && errors && b0 + threadIdx.x < B) {
-        const int i = threadIdx.x;
-        const double s = part[0][i] + part[1][i] + part[2][i] + part[3][i];
-        if (s != 0.0)
-            atomicAdd(&errors[(size_t)(b0 + i) * errors_stride], s * scale);
-    }
+    for (int e = cnt; e < NS; e++)
+        nyx[(size_t)idx * NS + e] = 0;
+    ncu[idx] = cnt | (cu << 8);
 }
 
 // ---------------------------------------------------------------------------------------
-// FWD: G = (depth-to-space of the residuals) = M - C * Y[. - D]   (+ exact near band), MSE trace
+// FWD: G = (depth-to-space of the residuals) = M - C * Y[. - D]   (near band: M - sum of the listed Y samples), MSE trace
 //   ZERO = false: Y = FIR_f(P(bpad)) computed per tile in LDS.   grid over the G plane [Hg, Wg], block 256.
 //   ZERO = true : Y[P, Q] = bpad[P+1, Q+1]                        (no LDS, pure index map)
 // ---------------------------------------------------------------------------------------
-// 1 / max(C, 1) for a count C (a small non-negative integer stored as T; the numerator is 0 where C == 0).  float: v_rcp_f32 (1 ulp;
-// the MSE trace is a float64 sum of ~1e7 such terms, compared to 1e-6 relative); double: the exact quotient.
+// 1 / max(C, 1) for a count C (a small non-negative integer stored as T; the numerator is 0 where C == 0).
+// float: v_rcp_f32 (1 ulp; the MSE trace is a float64 sum of ~1e7 such terms, compared to 1e-6 relative); double: exact.
 __device__ __forceinline__ float rcp_count(float c) { return __builtin_amdgcn_rcpf(fmaxf(c, 1.f)); }
 __device__ __forceinline__ double rcp_count(double c) { return 1.0 / fmax(c, 1.0); }
 
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
     k_fwd_mosaic(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
-                 int Wg, MosaicArgs<T> ma, T *__restrict__ Yb, T *__restrict__ G, double *__restrict__ errors,
+                 int Wg, MosaicArgs<T> ma, const T *__restrict__ Mu, const int *__restrict__ ncu,
+                 const int *__restrict__ nyx, int NS, int NB, T *__restrict__ G, double *__restrict__ errors,
                  int errors_stride, double scale, int dbg)
 {
     constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
@@ -331,12 +277,13 @@ __global__ void __launch_bounds__(256)
             fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? 12 : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
             SRX_STAMP(0, 1);
-            // rows / columns of Y this tile reads or publishes: [p0 - Dy, p0 - Dy + TS) x [q0 - Dx, q0 - Dx + TS)
+            // rows / columns of Y this tile's far field reads: [p0 - Dy, p0 - Dy + TS) x [q0 - Dx, q0 - Dx + TS); a
+            // tile of the near band also reads the first rows / columns (pa = 0 / qa = 0 there)
             const int r_lo = max(0, p0 - ma.Dy - pa), r_hi = min(nr - 3, p0 - ma.Dy + TS - pa);
-            fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid, r_lo);
+            const int r_lo_w = p0 < ma.PBy ? 0 : r_lo, c_lo_w = q0 < ma.PBx ? 0 : max(0, q0 - ma.Dx - qa);
+            fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid, r_lo_w);
             SRX_STAMP(0, 2);
-            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc, qa == 0, ma.wfx, tid,
-                                              max(0, q0 - ma.Dx - qa));
+            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo_w * LD, LD, max(r_hi - r_lo_w, 0), nc, qa == 0, ma.wfx, tid, c_lo_w);
         }
         __syncthreads();
         SRX_STAMP(0, 3);
@@ -347,21 +294,17 @@ __global__ void __launch_bounds__(256)
     };
     double sq = 0.0;
     T sqt = 0;
-    // ---- far field: one Y sample per pixel.  Pixels of the near band (first PBy rows / PBx columns, where LR
-    // row/column 0 is edge-replicated into the pad and frames subtract different Y samples) are left to
-    // k_fwd_near; this kernel only publishes the Y rows/columns they read (Yb).
+    // ---- far field: one Y sample per pixel.
     // Thread (prow + j * RPJ, pcol) of the tile; everything that does not depend on j is hoisted by hand and the
     // indices stay 32-bit (a batch chunk is < 2^31 elements): the unrolled pixel phase used to be ~45 % of this
     // kernel's VALU instructions, most of them 64-bit index arithmetic, predicates and the IEEE division.
     constexpr int RPJ = 256 / TS;
     const int prow = tid / TS, pcol = tid % TS;
     const int qg = q0 + pcol, Q = qg - ma.Dx;
-    const bool qok = qg < Wg && !(dbg & 8), qfar = qg >= ma.PBx;
-    const bool qpub = !ZERO && Q >= 0 && Q <= Wp - 4, qlow = Q < ma.YBx;
+    const bool qok = qg < Wg && qg >= ma.PBx && !(dbg & 8);
     T *Gp = G + (size_t)b * Hg * Wg + qg;
-    T *Yp = Yb + (size_t)b * Hp * Wp + Q;
-    const bool fast = p0 >= ma.PBy && q0 >= ma.PBx && p0 + TS <= Hg && q0 + TS <= Wg &&
-                      (ZERO || (p0 - ma.Dy >= ma.YBy && q0 - ma.Dx >= ma.YBx)) && !(dbg & 8);  // block-uniform
+    const bool has_near = p0 < ma.PBy || q0 < ma.PBx;                                      // block-uniform
+    const bool fast = !has_near && p0 + TS <= Hg && q0 + TS <= Wg && !(dbg & 8);  // block-uniform
     // all of this thread's Y samples first, unconditionally (clamped into the region: values of pixels that are
     // not stored are never used), so that the LDS reads are one batch instead of one round trip per pixel
     T Yv[NPX];
@@ -371,7 +314,7 @@ __global__ void __launch_bounds__(256)
         Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
     }
     if (fast) {
-        // interior tile: every pixel is far field and inside the plane, nothing to publish
+        // interior tile: every pixel is far field and inside the plane
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             const int pg = p0 + prow + j * RPJ;
@@ -382,16 +325,74 @@ __global__ void __launch_bounds__(256)
     } else {
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
-            const int pg = p0 + prow + j * RPJ, P = pg - ma.Dy;
-            if (pg >= Hg || !qok)
-                continue;
-            if (qpub && P >= 0 && P <= Hp - 4 && (qlow || P < ma.YBy))
-                Yp[P * Wp] = Yv[j];
-            if (!(qfar && pg >= ma.PBy))
+            const int pg = p0 + prow + j * RPJ;
+            if (pg >= Hg || pg < ma.PBy || !qok)
                 continue;
             const T g = Cv[j] > (T)0 ? Mv[j] - Cv[j] * Yv[j] : (T)0;  // Yv may be LDS garbage where C = 0
             sqt += g * g * rcp_count(Cv[j]);
             Gp[pg * Wg] = g;
+        }
+    }
+    // ---- near band of this tile: its first ntop rows and, below them, its first ncl columns, NEAR_B pixels per
+    // thread and trip with the table loads of a trip issued together
+    if (has_near && !(dbg & 8)) {
+        constexpr int NEAR_B = 4;
+        const int ntop = min(max(ma.PBy - p0, 0), TS), ncl = min(max(ma.PBx - q0, 0), TS), ncl1 = max(ncl, 1);
+        const int ntopc = ntop * TS, nn = ntopc + (TS - ntop) * ncl;
+        const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
+        T *Gb = G + (size_t)b * Hg * Wg;
+        const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
+        const int NS4 = NS >> 2;
+        for (int base = 0; base < nn; base += 256 * NEAR_B) {
+            int gi[NEAR_B], ni[NEAR_B], pk[NEAR_B], PQ[NEAR_B];
+            int4 c0[NEAR_B];
+            T mv[NEAR_B], mu[NEAR_B];
+            bool ok[NEAR_B];
+#pragma unroll
+            for (int i = 0; i < NEAR_B; i++) {
+                const int t = base + tid + 256 * i;
+                int pr, qc;
+                if (t < ntopc) {
+                    pr = t / TS, qc = t % TS;
+                } else {
+                    const int u = t - ntopc, r = u / ncl1;
+                    pr = ntop + r, qc = u - r * ncl1;
+                }
+                const int pg = p0 + pr, qn = q0 + qc;
+                ok[i] = t < nn && pg < Hg && qn < Wg;
+                ni[i] = ok[i] ? near_index(pg, qn, Wg, ma.PBy, ma.PBx) : 0;
+                gi[i] = ok[i] ? pg * Wg + qn : 0;
+                PQ[i] = ok[i] ? (max(pg - ma.Dy, 0) | (max(qn - ma.Dx, 0) << 16)) : 0;  // own Y sample, if it has one
+                pk[i] = ncu[ni[i]];
+                c0[i] = nyx4[(size_t)ni[i] * NS4];
+                mv[i] = Mgb[gi[i]];
+                mu[i] = Mub[ni[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < NEAR_B; i++) {
+                if (!ok[i])
+                    continue;
+                const int cnt = pk[i] & 255, cu = pk[i] >> 8;
+                const int cv[4] = {c0[i].x, c0[i].y, c0[i].z, c0[i].w};
+                T ys = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (e < cnt)
+                        ys += Y(cv[e] & 0xffff, cv[e] >> 16);
+                for (int e0 = 4; e0 < cnt; e0 += 4) {  // only where both axes replicate (the corner) or frames share a phase
+                    const int4 c = nyx4[(size_t)ni[i] * NS4 + (e0 >> 2)];
+                    const int ce[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (e0 + e < cnt)
+                            ys += Y(ce[e] & 0xffff, ce[e] >> 16);
+                }
+                Gb[gi[i]] = mv[i] - ys;
+                if (cu > 0) {
+                    const T gu = mu[i] - (T)cu * Y(PQ[i] & 0xffff, PQ[i] >> 16);
+                    sqt += gu * gu * rcp_count((T)cu);
+                }
+            }
         }
     }
     SRX_STAMP(0, 4);
@@ -612,9 +613,10 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
 {
     const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
     const size_t NBmax = 20 * (Hg + Wg);  // near band: PB <= 18 rows + 18 columns of the plane
-    return 2 * align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
-           2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double)) +
-           align_up(NBmax * sizeof(int)) + align_up(NBmax * N * sizeof(NEnt));
+    const size_t NS = (N + 3) & ~3;
+    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
+           align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
+           align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int));
 }
 
 template <typename T>
@@ -628,12 +630,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
-    T *pad = ar.take<T>((size_t)B * Hp * Wp), *Yb = ar.take<T>((size_t)B * Hp * Wp);
+    const int NS = (N + 3) & ~3;                        // slots per near-band pixel
+    T *pad = ar.take<T>((size_t)B * Hp * Wp);
     T *G = ar.take<T>((size_t)B * Hg * Wg), *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
+    T *Mu = ar.take<T>((size_t)B * NB);
     MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = ar.take<double>(B);
-    int *ncnt = ar.take<int>(NB);
-    NEnt *nent = ar.take<NEnt>((size_t)NB * N);
+    int *ncu = ar.take<int>(NB), *nyx = ar.take<int>((size_t)NB * NS);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
@@ -642,7 +645,6 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         dy.n[q] = q < N ? py.n[q] : 0, dx.n[q] = q < N ? px.n[q] : 0;
     MosaicArgs<T> ma;
     ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB;
-    ma.YBy = py.E + py.PB - 13 + 1, ma.YBx = px.E + px.PB - 13 + 1;  // E - n_min + 1
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
     for (int i = 0; i < 4; i++)
@@ -673,10 +675,9 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
     SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, N, h, w, tabY,
-               tabX, Hg, Wg, py.PB, px.PB, Mg, Cg, Vtot);
-    const bool zero_ = py.zero && px.zero;
-    hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, h, w, Hg, Wg, py.PB, px.PB, py.D,
-                       px.D, zero_ ? 1 : 0, H, W, NB, ncnt, nent);
+               tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+    hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
+                       NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     if (errors) {
@@ -696,17 +697,12 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
-        if (zero) {
-            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
-                       eo, n_iter, scale, dbg);
-            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
-                       (size_t)N * h * w, pad, (size_t)H * W, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
-        } else {
-            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), dbg_lds, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Yb, G,
-                       eo, n_iter, scale, dbg);
-            SRX_LAUNCH(KID_FWD_NEAR, k_fwd_near<T>, dim3(cdiv(NB, 256), cdiv(B, NEAR_IB)), dim3(256), 0, st, lr,
-                       (size_t)N * h * w, Yb, (size_t)Hp * Wp, N, B, Hg, Wg, py.PB, px.PB, NB, ncnt, nent, G, eo, n_iter, scale);
-        }
+        if (zero)
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Mu, ncu,
+                       nyx, NS, NB, G, eo, n_iter, scale, dbg);
+        else
+            SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), dbg_lds, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma,
+                       Mu, ncu, nyx, NS, NB, G, eo, n_iter, scale, dbg);
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, dbg)
         if (zero) {
@@ -766,7 +762,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         fo.oy[q] = q < N ? -py.n[q] - (py.zero ? 1 : 2) : 0;
         fo.ox[q] = q < N ? -px.n[q] - (px.zero ? 1 : 2) : 0;
     }
-    ma.Dy = ma.Dx = ma.PBy = ma.PBx = ma.YBy = ma.YBx = 0;
+    ma.Dy = ma.Dx = ma.PBy = ma.PBx = 0;
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
     for (int i = 0; i < 4; i++)
