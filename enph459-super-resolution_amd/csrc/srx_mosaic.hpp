@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256)
             cu += (ty.rho == p - Dy && tx.rho == q - Dx) ? 1 : 0;
         }
     }
-    for (int e = cnt; e < NS; e++)
-        nyx[(size_t)idx * NS + e] = 0;
+    for (int e = cnt; e < NS; e++)  // padding: a coordinate that is inside the region of the tile holding this pixel
+        nyx[(size_t)idx * NS + e] = max(p - Dy, 0) | (max(q - Dx, 0) << 16);
     ncu[idx] = cnt | (cu << 8);
 }
 
@@ -313,6 +313,42 @@ __global__ void __launch_bounds__(256)
         const int P = p0 + prow + j * RPJ - ma.Dy;
         Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
     }
+    // ---- near band of this tile: its first ntop rows and, below them, its first ncl columns, NEAR_B pixels per
+    // thread and trip.  The table loads of a trip are issued together, the first trip's before the far-field pass
+    constexpr int NEAR_B = 5;
+    const int ntop = min(max(ma.PBy - p0, 0), TS), ncl = min(max(ma.PBx - q0, 0), TS), ncl1 = max(ncl, 1);
+    const int ntopc = ntop * TS, nn = (dbg & 8) ? 0 : ntopc + (TS - ntop) * ncl;  // 0 unless has_near
+    const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
+    T *Gb = G + (size_t)b * Hg * Wg;
+    const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
+    const int NS4 = NS >> 2;
+    int gi[NEAR_B], ni[NEAR_B], pk[NEAR_B], PQ[NEAR_B];
+    int4 c0[NEAR_B];
+    T mv[NEAR_B], mu[NEAR_B];
+    auto near_load = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < NEAR_B; i++) {
+            const int t = base + tid + 256 * i;
+            int pr, qc;
+            if (t < ntopc) {
+                pr = t / TS, qc = t % TS;
+            } else {
+                const int u = t - ntopc, r = u / ncl1;
+                pr = ntop + r, qc = u - r * ncl1;
+            }
+            const int pg = p0 + pr, qn = q0 + qc;
+            const bool ok = t < nn && pg < Hg && qn < Wg;
+            ni[i] = ok ? near_index(pg, qn, Wg, ma.PBy, ma.PBx) : 0;
+            gi[i] = ok ? pg * Wg + qn : -1;
+            PQ[i] = max(pg - ma.Dy, 0) | (max(qn - ma.Dx, 0) << 16);  // own Y sample, if it has one
+            pk[i] = ncu[ni[i]];
+            c0[i] = nyx4[(size_t)ni[i] * NS4];
+            mv[i] = Mgb[max(gi[i], 0)];
+            mu[i] = Mub[ni[i]];
+        }
+    };
+    if (nn > 0)
+        near_load(0);
     if (fast) {
         // interior tile: every pixel is far field and inside the plane
 #pragma unroll
@@ -333,67 +369,46 @@ __global__ void __launch_bounds__(256)
             Gp[pg * Wg] = g;
         }
     }
-    // ---- near band of this tile: its first ntop rows and, below them, its first ncl columns, NEAR_B pixels per
-    // thread and trip with the table loads of a trip issued together
-    if (has_near && !(dbg & 8)) {
-        constexpr int NEAR_B = 4;
-        const int ntop = min(max(ma.PBy - p0, 0), TS), ncl = min(max(ma.PBx - q0, 0), TS), ncl1 = max(ncl, 1);
-        const int ntopc = ntop * TS, nn = ntopc + (TS - ntop) * ncl;
-        const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
-        T *Gb = G + (size_t)b * Hg * Wg;
-        const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
-        const int NS4 = NS >> 2;
-        for (int base = 0; base < nn; base += 256 * NEAR_B) {
-            int gi[NEAR_B], ni[NEAR_B], pk[NEAR_B], PQ[NEAR_B];
-            int4 c0[NEAR_B];
-            T mv[NEAR_B], mu[NEAR_B];
-            bool ok[NEAR_B];
+    for (int base = 0; base < nn;) {
+        // slots past cnt hold the pixel's own (clamped) coordinate, so every read is in range and unconditional
+        T ys[NEAR_B], yn[NEAR_B];
+        int cmax = 0;
+#pragma unroll
+        for (int i = 0; i < NEAR_B; i++) {
+            const int cnt = pk[i] & 255;
+            const T y0 = Y(c0[i].x & 0xffff, c0[i].x >> 16), y1 = Y(c0[i].y & 0xffff, c0[i].y >> 16);
+            const T y2 = Y(c0[i].z & 0xffff, c0[i].z >> 16), y3 = Y(c0[i].w & 0xffff, c0[i].w >> 16);
+            yn[i] = Y(PQ[i] & 0xffff, PQ[i] >> 16);
+            ys[i] = (cnt > 0 ? y0 : (T)0) + (cnt > 1 ? y1 : (T)0) + (cnt > 2 ? y2 : (T)0) + (cnt > 3 ? y3 : (T)0);
+            cmax = max(cmax, gi[i] < 0 ? 0 : cnt);
+        }
+        // more than 4 frames on a pixel: only where both axes replicate (the corner) or frames share a phase.  One
+        // slot of all NEAR_B pixels per trip, so a trip pays one table latency
+        for (int e0 = 4; e0 < cmax; e0 += 4) {
+            int4 c[NEAR_B];
+#pragma unroll
+            for (int i = 0; i < NEAR_B; i++)
+                c[i] = nyx4[(size_t)ni[i] * NS4 + (e0 >> 2)];
 #pragma unroll
             for (int i = 0; i < NEAR_B; i++) {
-                const int t = base + tid + 256 * i;
-                int pr, qc;
-                if (t < ntopc) {
-                    pr = t / TS, qc = t % TS;
-                } else {
-                    const int u = t - ntopc, r = u / ncl1;
-                    pr = ntop + r, qc = u - r * ncl1;
-                }
-                const int pg = p0 + pr, qn = q0 + qc;
-                ok[i] = t < nn && pg < Hg && qn < Wg;
-                ni[i] = ok[i] ? near_index(pg, qn, Wg, ma.PBy, ma.PBx) : 0;
-                gi[i] = ok[i] ? pg * Wg + qn : 0;
-                PQ[i] = ok[i] ? (max(pg - ma.Dy, 0) | (max(qn - ma.Dx, 0) << 16)) : 0;  // own Y sample, if it has one
-                pk[i] = ncu[ni[i]];
-                c0[i] = nyx4[(size_t)ni[i] * NS4];
-                mv[i] = Mgb[gi[i]];
-                mu[i] = Mub[ni[i]];
-            }
-#pragma unroll
-            for (int i = 0; i < NEAR_B; i++) {
-                if (!ok[i])
-                    continue;
-                const int cnt = pk[i] & 255, cu = pk[i] >> 8;
-                const int cv[4] = {c0[i].x, c0[i].y, c0[i].z, c0[i].w};
-                T ys = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (e < cnt)
-                        ys += Y(cv[e] & 0xffff, cv[e] >> 16);
-                for (int e0 = 4; e0 < cnt; e0 += 4) {  // only where both axes replicate (the corner) or frames share a phase
-                    const int4 c = nyx4[(size_t)ni[i] * NS4 + (e0 >> 2)];
-                    const int ce[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (e0 + e < cnt)
-                            ys += Y(ce[e] & 0xffff, ce[e] >> 16);
-                }
-                Gb[gi[i]] = mv[i] - ys;
-                if (cu > 0) {
-                    const T gu = mu[i] - (T)cu * Y(PQ[i] & 0xffff, PQ[i] >> 16);
-                    sqt += gu * gu * rcp_count((T)cu);
-                }
+                const int cnt = (pk[i] & 255) - e0;
+                const T y0 = Y(c[i].x & 0xffff, c[i].x >> 16), y1 = Y(c[i].y & 0xffff, c[i].y >> 16);
+                const T y2 = Y(c[i].z & 0xffff, c[i].z >> 16), y3 = Y(c[i].w & 0xffff, c[i].w >> 16);
+                ys[i] += (cnt > 0 ? y0 : (T)0) + (cnt > 1 ? y1 : (T)0) + (cnt > 2 ? y2 : (T)0) + (cnt > 3 ? y3 : (T)0);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NEAR_B; i++) {
+            if (gi[i] < 0)
+                continue;
+            const int cu = pk[i] >> 8;
+            Gb[gi[i]] = mv[i] - ys[i];
+            const T gu = cu > 0 ? mu[i] - (T)cu * yn[i] : (T)0;
+            sqt += gu * gu * rcp_count((T)cu);
+        }
+        base += 256 * NEAR_B;
+        if (base < nn)
+            near_load(base);
     }
     SRX_STAMP(0, 4);
     sq = wave_sum(sq + (double)sqt);

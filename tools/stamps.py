@@ -32,4 +32,7 @@ for k, (kn, ph) in names.items():
     print(f"{kn}: blocks {ok.sum()}, median cycles/block {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f})")
     for i in range(5):
         d = (t[i + 1, :nb] - t[i, :nb])[ok]
-        print(f"    {ph[i + 1]:22s} median {np.median(d):8.0f}  share {100 * np.median(d) / np.median(tot):5.1f} %")
+        print(f"    {ph[i + 1]:22s} median {np.median(d):8.0f}  mean {d.mean():8.0f}  share of mean {100 * d.mean() / tot.mean():5.1f} %")
+    if k == 0:  # fwd: 5 x 5 tiles per item, x fastest -- edge classes (assumes the C2 shape and no XCD remap effect on class sizes)
+        d = (t[4, :nb] - t[3, :nb])[ok]
+        print(f"    pixel phase percentiles 10/50/75/90/99: {np.percentile(d, [10, 50, 75, 90, 99]).round(0)}")
