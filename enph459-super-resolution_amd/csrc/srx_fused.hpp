@@ -207,6 +207,38 @@ __device__ __forceinline__ void load_region(T *__restrict__ reg, int ld, const T
     }
 }
 
+// Same, but region cell (rr, cc) is plane[max(pa + rr, rlo)][max(qa + cc, clo)]: the first rlo rows / clo columns of
+// the plane are replicas of row rlo / column clo that nobody wrote (the mosaic's G plane).
+template <typename T, int MAXR, int MAXC, int BATCH = 8>
+__device__ __forceinline__ void load_region_lo(T *__restrict__ reg, int ld, const T *__restrict__ plane, int pitch, int pa,
+                                               int qa, int rlo, int clo, int nr, int nc, int wave, int lane)
+{
+    constexpr int RPW = (MAXR + 3) / 4, CPL = (MAXC + 63) / 64;
+    int col[CPL];
+#pragma unroll
+    for (int cc = 0; cc < CPL; cc++)
+        col[cc] = max(qa + min(lane + 64 * cc, nc - 1), clo);
+#pragma unroll
+    for (int j0 = 0; j0 < RPW; j0 += BATCH) {
+        T v[BATCH][CPL];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int row = max(pa + min(wave + 4 * (j0 + j), nr - 1), rlo);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                v[j][cc] = plane[row * pitch + col[cc]];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int rr = wave + 4 * (j0 + j);
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc++)
+                if (rr < nr && lane + 64 * cc < nc)
+                    reg[rr * ld + lane + 64 * cc] = v[j][cc];
+        }
+    }
+}
+
 // Same, but the source is an UNPADDED image plane [H, W] read as its 12-px edge-replicated extension: region cell
 // (rr, cc) is padded coordinate (pa + rr, qa + cc) = image pixel (clamp(pa+rr-12), clamp(qa+cc-12)).  SciPy's
 // np.pad(mode='edge') is thus never materialised on the iteration path.

@@ -53,7 +53,7 @@ using fused::TileCfg;
 
 struct AxisPlan {
     double delta;
-    int zero, E, D, PB;
+    int zero, E, D, PB, RS;
     int n[SRX_MAX_FRAMES];
 };
 
@@ -64,6 +64,7 @@ struct AxisDev {  // kernel-argument part of a plan
 
 template <typename T> struct MosaicArgs {
     int Dy, Dx, PBy, PBx;  // G coordinates p' < PB form the near band (edge-replicated LR row/column 0)
+    int RSy, RSx;          // ... of which rows <= RSy (columns <= RSx) are identical: only row RSy is computed and stored
     T wfy[4], wfx[4];  // forward FIR (after the prefilter)
     T wby[4], wbx[4];  // backward FIR (before the prefilter)
 };
@@ -95,7 +96,13 @@ static inline bool plan_axis(int N, const double *sh, int axis, int f, AxisPlan 
     int nmin = pl.n[0];
     for (int k = 1; k < N; k++)
         nmin = std::min(nmin, pl.n[k]);
+    int nmax = pl.n[0];
+    for (int k = 1; k < N; k++)
+        nmax = std::max(nmax, pl.n[k]);
     pl.PB = 13 - nmin;
+    // For p' <= 13 - n_max every frame has u = p' + n_k - 13 <= 0, i.e. it contributes its LR row 0 and subtracts Y row
+    // E - n_k, whether by replication (u < 0) or as its own sample (u = 0): those rows of G are all equal to row RS.
+    pl.RS = std::max(13 - nmax, 0);
     return true;
 }
 
@@ -313,11 +320,13 @@ __global__ void __launch_bounds__(256)
         const int P = p0 + prow + j * RPJ - ma.Dy;
         Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
     }
-    // ---- near band of this tile: its first ntop rows and, below them, its first ncl columns, NEAR_B pixels per
-    // thread and trip.  The table loads of a trip are issued together, the first trip's before the far-field pass
-    constexpr int NEAR_B = 5;
-    const int ntop = min(max(ma.PBy - p0, 0), TS), ncl = min(max(ma.PBx - q0, 0), TS), ncl1 = max(ncl, 1);
-    const int ntopc = ntop * TS, nn = (dbg & 8) ? 0 : ntopc + (TS - ntop) * ncl;  // 0 unless has_near
+    // ---- near band of this tile, without the replicated rows < RSy / columns < RSx (nobody computes those: the
+    // backward kernel reads row RSy / column RSx instead), NEAR_B pixels per thread and trip.  The table loads of a trip are issued together, the first trip's before the far-field pass
+    constexpr int NEAR_B = 2;
+    // top part: rows [rt0, rt0 + ntop) x columns [ct0, q0 + TS); left part: rows [rl0, p0 + TS) x columns [ct0, ct0 + ncl)
+    const int rt0 = max(p0, ma.RSy), ntop = max(min(ma.PBy, p0 + TS) - rt0, 0), ct0 = max(q0, ma.RSx), nct = q0 + TS - ct0;
+    const int rl0 = max(p0, ma.PBy), ncl = max(min(ma.PBx, q0 + TS) - ct0, 0), ncl1 = max(ncl, 1);
+    const int ntopc = ntop * nct, nn = (dbg & 8) ? 0 : ntopc + (p0 + TS - rl0) * ncl;  // 0 unless has_near
     const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
     T *Gb = G + (size_t)b * Hg * Wg;
     const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
@@ -329,14 +338,14 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int i = 0; i < NEAR_B; i++) {
             const int t = base + tid + 256 * i;
-            int pr, qc;
+            int pg, qn;
             if (t < ntopc) {
-                pr = t / TS, qc = t % TS;
+                const int r = t / nct;
+                pg = rt0 + r, qn = ct0 + t - r * nct;
             } else {
                 const int u = t - ntopc, r = u / ncl1;
-                pr = ntop + r, qc = u - r * ncl1;
+                pg = rl0 + r, qn = ct0 + u - r * ncl1;
             }
-            const int pg = p0 + pr, qn = q0 + qc;
             const bool ok = t < nn && pg < Hg && qn < Wg;
             ni[i] = ok ? near_index(pg, qn, Wg, ma.PBy, ma.PBx) : 0;
             gi[i] = ok ? pg * Wg + qn : -1;
@@ -454,10 +463,10 @@ __global__ void __launch_bounds__(256)
             hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
     if (ZERO) {
         // c'[p, q] = G[p+1, q+1]
-        fused::load_region<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src + (size_t)(pa + 1) * Wg + qa + 1, Wg, nr, nc, wave, lane);
+        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
         __syncthreads();
     } else {
-        fused::load_region<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src + (size_t)pa * Wg + qa, Wg, nr + 3, nc + 3, wave, lane);
+        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Wg, pa, qa, ma.RSy, ma.RSx, nr + 3, nc + 3, wave, lane);
         __syncthreads();
         SRX_STAMP(1, 1);
         constexpr int RW = TileCfg<T>::R;
@@ -659,7 +668,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     for (int q = 0; q < SRX_MAX_FRAMES; q++)
         dy.n[q] = q < N ? py.n[q] : 0, dx.n[q] = q < N ? px.n[q] : 0;
     MosaicArgs<T> ma;
-    ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB;
+    ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB, ma.RSy = py.RS, ma.RSx = px.RS;
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
     for (int i = 0; i < 4; i++)
@@ -777,7 +786,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         fo.oy[q] = q < N ? -py.n[q] - (py.zero ? 1 : 2) : 0;
         fo.ox[q] = q < N ? -px.n[q] - (px.zero ? 1 : 2) : 0;
     }
-    ma.Dy = ma.Dx = ma.PBy = ma.PBx = 0;
+    ma.Dy = ma.Dx = ma.PBy = ma.PBx = ma.RSy = ma.RSx = 0;
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
     for (int i = 0; i < 4; i++)
