@@ -66,6 +66,7 @@ enum KernelId {
     KID_FWD_MOSAIC,
     KID_BWD_MOSAIC,
     KID_SAA_TILE,
+    KID_PREFILTER_SMALL,
     KID_COUNT
 };
 

@@ -148,45 +148,73 @@ __device__ __forceinline__ int near_index(int p, int q, int Wg, int PBy, int PBx
 // at their own (unreplicated) position, the ones the MSE trace counts.  V = sum over pixels of the within-pixel
 // scatter sum_k (l_k - mean)^2 of the counted samples (constant over the iterations; non-zero only where two
 // frames share a phase)
+#define MOSAIC_IB 8  // batch items per thread: the tap tables are per (frame, coordinate), shared by all items
 template <typename T>
 __global__ void __launch_bounds__(256)
-    k_mosaic_build(const T *__restrict__ lr, int N, int h, int w, const MTap *__restrict__ tabY,
+    k_mosaic_build(const T *__restrict__ lr, int B, int N, int h, int w, const MTap *__restrict__ tabY,
                    const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
                    T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot)
 {
-    __shared__ double part[4];
-    const int q = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
-    double var = 0.0;
+    __shared__ double part[4][MOSAIC_IB];
+    const int q = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b0 = blockIdx.z * MOSAIC_IB;
+    const size_t item = (size_t)N * h * w;
+    double var[MOSAIC_IB];
+#pragma unroll
+    for (int i = 0; i < MOSAIC_IB; i++)
+        var[i] = 0.0;
     if (p < Hg && q < Wg) {
-        const bool nearpx = p < PBy || q < PBx;
-        double M = 0.0, S1 = 0.0, S2 = 0.0;  // S1, S2: over the counted samples
+        double M[MOSAIC_IB], S1[MOSAIC_IB], S2[MOSAIC_IB];  // S1, S2: over the counted samples
+#pragma unroll
+        for (int i = 0; i < MOSAIC_IB; i++)
+            M[i] = S1[i] = S2[i] = 0.0;
         int C = 0, Cu = 0;
         for (int k = 0; k < N; k++) {
             const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
-            if (ty.i >= 0 && tx.i >= 0) {
-                const double l = (double)lr[(((size_t)b * N + k) * h + ty.i) * w + tx.i];
-                M += l;
-                C++;
-                if (ty.rho == p - Dy && tx.rho == q - Dx)
-                    S1 += l, S2 += l * l, Cu++;
+            if (ty.i < 0 || tx.i < 0)
+                continue;
+            const bool counted = ty.rho == p - Dy && tx.rho == q - Dx;
+            const T *src = lr + (size_t)(k * h + ty.i) * w + tx.i;
+            T l[MOSAIC_IB];
+#pragma unroll
+            for (int i = 0; i < MOSAIC_IB; i++)
+                l[i] = src[(size_t)min(b0 + i, B - 1) * item];  // clamped duplicate for a ragged last group; dropped below
+            C++;
+            Cu += counted ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < MOSAIC_IB; i++) {
+                const double lv = (double)l[i];
+                M[i] += lv;
+                if (counted)
+                    S1[i] += lv, S2[i] += lv * lv;
             }
         }
-        Mg[((size_t)b * Hg + p) * Wg + q] = (T)M;
-        if (b == 0)
+        if (b0 == 0)
             Cg[(size_t)p * Wg + q] = (T)C;
-        if (nearpx)
-            Mu[(size_t)b * NB + near_index(p, q, Wg, PBy, PBx)] = (T)S1;
-        if (Cu > 1)
-            var = S2 - S1 * S1 / (double)Cu;
+        const bool nearpx = p < PBy || q < PBx;
+        const int ni = nearpx ? near_index(p, q, Wg, PBy, PBx) : 0;
+#pragma unroll
+        for (int i = 0; i < MOSAIC_IB; i++) {
+            if (b0 + i >= B)
+                continue;
+            Mg[((size_t)(b0 + i) * Hg + p) * Wg + q] = (T)M[i];
+            if (nearpx)
+                Mu[(size_t)(b0 + i) * NB + ni] = (T)S1[i];
+            if (Cu > 1)
+                var[i] = S2[i] - S1[i] * S1[i] / (double)Cu;
+        }
     }
-    var = wave_sum(var);
-    if (threadIdx.x == 0)
-        part[threadIdx.y] = var;
+#pragma unroll
+    for (int i = 0; i < MOSAIC_IB; i++) {
+        const double v = wave_sum(var[i]);
+        if (threadIdx.x == 0)
+            part[threadIdx.y][i] = v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        const double s = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.y == 0 && threadIdx.x < MOSAIC_IB && b0 + threadIdx.x < B) {
+        const int i = threadIdx.x;
+        const double s = part[0][i] + part[1][i] + part[2][i] + part[3][i];
         if (s != 0.0)
-            atomicAdd(&Vtot[b], s);
+            atomicAdd(&Vtot[b0 + i], s);
     }
 }
 
@@ -533,6 +561,59 @@ __global__ void __launch_bounds__(256)
 // the tile like in k_bwd_mosaic.  zoom(order=3) semantics (corner-aligned, mirrored taps) come from the same
 // device-built tap tables as srx_zoom_cubic.
 // ---------------------------------------------------------------------------------------
+// spline_filter(order 3, mode) of frames that fit a wave: h, w <= 64.  One wave per frame, the frame in LDS (row
+// stride 65: conflict-free both ways), lane = column for axis 0, lane = row for axis 1; whole lines, so SciPy's exact
+// boundary sums at both ends and no warm-up.  Replaces copy + k_prefilter_axis0 + k_prefilter_axis1 (out of place,
+// chunked, for long lines) on the LR stacks of shift_and_add.  grid ceil(frames / 4), block 256.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_prefilter_small(const T *__restrict__ src_, T *__restrict__ dst_, int nframes, int Hc, int Wc, int mode)
+{
+    constexpr int LD = 65;
+    __shared__ T buf[4][64 * LD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fr = min((int)blockIdx.x * 4 + wave, nframes - 1);  // a ragged last block repeats the last frame
+    const T *src = src_ + (size_t)fr * Hc * Wc;
+    T *dst = dst_ + (size_t)fr * Hc * Wc;
+    T *reg = buf[wave];
+    const int cl = min(lane, Wc - 1);
+    for (int r0 = 0; r0 < Hc; r0 += 16) {
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            v[u] = src[(size_t)min(r0 + u, Hc - 1) * Wc + cl];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (r0 + u < Hc && lane < Wc)
+                reg[(r0 + u) * LD + lane] = v[u];
+    }
+    __syncthreads();
+    fused::WalkState<T> st;
+    if (lane < Wc && Hc > 1) {
+        T *line = reg + lane;
+        st.prev = causal_init<T>([&](int q) { return (T)6 * line[q * LD]; }, Hc, mode);
+        line[0] = st.prev;
+        fused::causal_run<T, LD, 0>(line, 1, Hc, st, (T)0, (T)0, (T)0, (T)0);
+        st.next = anticausal_init<T>(st.prev, line[(Hc - 2) * LD], mode);
+        line[(Hc - 1) * LD] = st.next;
+        fused::anticausal_run<T, LD, 0>(line, Hc - 2, 0, st, (T)0, (T)0, (T)0, (T)0);
+    }
+    __syncthreads();
+    if (lane < Hc && Wc > 1) {
+        T *line = reg + lane * LD;
+        st.prev = causal_init<T>([&](int q) { return (T)6 * line[q]; }, Wc, mode);
+        line[0] = st.prev;
+        fused::causal_run<T, 1, 0>(line, 1, Wc, st, (T)0, (T)0, (T)0, (T)0);
+        st.next = anticausal_init<T>(st.prev, line[Wc - 2], mode);
+        line[Wc - 1] = st.next;
+        fused::anticausal_run<T, 1, 0>(line, Wc - 2, 0, st, (T)0, (T)0, (T)0, (T)0);
+    }
+    __syncthreads();
+    for (int r = 0; r < Hc; r++)
+        if (lane < Wc)
+            dst[(size_t)r * Wc + lane] = reg[r * LD + lane];
+}
+
 struct FrameOffsets {
     int oy[SRX_MAX_FRAMES], ox[SRX_MAX_FRAMES];
 };
@@ -698,7 +779,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     SRX_CHECK_LAUNCH();
     if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
-    SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, N, h, w, tabY,
+    SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, MOSAIC_IB)), dim3(64, 4), 0, st, lr, B, N, h, w, tabY,
                tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
     hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
                        NB, ncu, nyx);
@@ -774,9 +855,14 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
     AxisTap<T> *zy = ar.take<AxisTap<T>>(H), *zx = ar.take<AxisTap<T>>(W);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return SRX_E_HIP;
-    SRX_TRY(prefilter2d(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+    if (h <= 64 && w <= 64) {
+        SRX_LAUNCH(KID_PREFILTER_SMALL, k_prefilter_small<T>, dim3(cdiv(B * N, 4)), dim3(256), 0, st, lr, coef, B * N, h, w,
+                   (int)MODE_MIRROR);
+    } else {
+        if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return SRX_E_HIP;
+        SRX_TRY(prefilter2d(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+    }
     SRX_TRY(build_taps(zy, H, h, TAP_ZOOM, 1, H > 1 ? (double)(h - 1) / (double)(H - 1) : 1.0, st));
     SRX_TRY(build_taps(zx, W, w, TAP_ZOOM, 1, W > 1 ? (double)(w - 1) / (double)(W - 1) : 1.0, st));
     FrameOffsets fo;
