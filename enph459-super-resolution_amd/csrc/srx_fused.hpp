@@ -514,8 +514,11 @@ template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
 // S = element stride, a compile-time constant: with a run-time stride hipcc must assume that the store of
 // step i aliases the load of step i+1 and serialises one LDS round trip (~150 cycles) per step.  Here 8
 // samples are read, run through the serial recursion in registers and written back per trip.
+// The recursions run in a scaled form with ONE dependent fma per step and direction:
+//   causal      p[i] = v[i] + z p[i-1]        (c+ = 6 p);  the line stores q[i] = -6 z p[i] = -z c+[i]
+//   anticausal  c[i] = z c[i+1] + q[i]        (= z (c[i+1] - c+[i]), SciPy's form)
 template <typename T> struct WalkState {
-    T prev;        // causal state c+[i-1]
+    T prev;        // causal state p[i-1] = c+[i-1] / 6
     T g0, g1, g2;  // MODE 1: the three newest FIR inputs
     T next;        // anticausal state c[i+1]
     T a1, a2, a3;  // MODE 2: c[i+1], c[i+2], c[i+3]
@@ -526,7 +529,7 @@ template <typename T, int S, int MODE>
 __device__ __forceinline__ void causal_run(T *__restrict__ line, int i0, int i1, WalkState<T> &st, T w0, T w1, T w2, T w3)
 {
     constexpr int U = 8, O = MODE == 1 ? 3 : 0;
-    const T z = pole<T>();
+    const T z = pole<T>(), kq = (T)-6 * z;
     int base = i0;
     for (; base + U <= i1; base += U) {
         T x[U];
@@ -540,8 +543,8 @@ __device__ __forceinline__ void causal_run(T *__restrict__ line, int i0, int i1,
                 v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * x[u];
                 st.g0 = st.g1, st.g1 = st.g2, st.g2 = x[u];
             }
-            st.prev = (T)6 * v + z * st.prev;
-            x[u] = st.prev;
+            st.prev = v + z * st.prev;
+            x[u] = kq * st.prev;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -554,8 +557,8 @@ __device__ __forceinline__ void causal_run(T *__restrict__ line, int i0, int i1,
             v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * g3;
             st.g0 = st.g1, st.g1 = st.g2, st.g2 = g3;
         }
-        st.prev = (T)6 * v + z * st.prev;
-        line[base * S] = st.prev;
+        st.prev = v + z * st.prev;
+        line[base * S] = kq * st.prev;
     }
 }
 
@@ -573,7 +576,7 @@ __device__ __forceinline__ void anticausal_run(T *__restrict__ line, int ihi, in
             x[u] = line[(i - u) * S];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            st.next = z * (st.next - x[u]);
+            st.next = z * st.next + x[u];
             if (MODE == 2) {
                 x[u] = w0 * st.next + w1 * st.a1 + w2 * st.a2 + w3 * st.a3;  // a valid FIR output for i-u <= n-4
                 st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
@@ -586,7 +589,7 @@ __device__ __forceinline__ void anticausal_run(T *__restrict__ line, int ihi, in
             line[(i - u) * S] = x[u];
     }
     for (; i >= ilo; i--) {
-        st.next = z * (st.next - line[i * S]);
+        st.next = z * st.next + line[i * S];
         if (MODE == 2) {
             line[i * S] = w0 * st.next + w1 * st.a1 + w2 * st.a2 + w3 * st.a3;
             st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
@@ -608,7 +611,7 @@ __device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, 
         T v0 = line[0];
         if (MODE == 1)
             v0 = w0 * line[0] + w1 * line[S] + w2 * line[2 * S] + w3 * line[3 * S];
-        st.prev = (T)6 * v0 / ((T)1 - z);
+        st.prev = v0 / ((T)1 - z);
     } else {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
         T zi = 1, acc = 0;
         const int kk = min(K, n);
@@ -625,7 +628,7 @@ __device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, 
             acc += zi * v;
             zi *= z;
         }
-        st.prev = (T)6 * acc;
+        st.prev = acc;
     }
     if (MODE == 1)
         st.g0 = line[0], st.g1 = line[S], st.g2 = line[2 * S];
@@ -641,7 +644,7 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
     st.g0 = st.g1 = st.g2 = 0;
     causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
     causal_run<T, S, MODE>(line, 0, n, st, w0, w1, w2, w3);
-    st.next = st.prev * (z / (z - (T)1));
+    st.next = st.prev * ((T)6 * z / (z - (T)1));
     st.a1 = st.next, st.a2 = 0, st.a3 = 0;
     if (MODE != 2)
         line[(n - 1) * S] = st.next;
@@ -658,7 +661,7 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
                                                const T *__restrict__ w, int tid, int need_lo = 0)
 {
     constexpr int O = MODE == 1 ? 3 : 0;
-    const T z = pole<T>(), zfin = z / (z - (T)1);
+    const T z = pole<T>(), zfin = z / (z - (T)1), kq = (T)-6 * z;
     const int n = MODE == 1 ? n_in - 3 : n_in;
     const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
     const int lineid = tid & 127, seg = tid >> 7;
@@ -707,8 +710,8 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
                     v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * x[u];
                     st.g0 = st.g1, st.g1 = st.g2, st.g2 = x[u];
                 }
-                st.prev = (T)6 * v + z * st.prev;
-                x[u] = st.prev;
+                st.prev = v + z * st.prev;
+                x[u] = kq * st.prev;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
@@ -717,18 +720,18 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
             // warm-up over the R pre-loaded samples [mid-R, mid), steady-state start
             if (MODE == 1) {
                 st.g0 = pre[0], st.g1 = pre[1], st.g2 = pre[2];
-                st.prev = (T)6 * (w0 * pre[0] + w1 * pre[1] + w2 * pre[2] + w3 * pre[3]) / ((T)1 - z);
+                st.prev = (w0 * pre[0] + w1 * pre[1] + w2 * pre[2] + w3 * pre[3]) / ((T)1 - z);
 #pragma unroll
                 for (int j = 0; j < R; j++) {
                     const T v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * pre[j + 3];
                     st.g0 = st.g1, st.g1 = st.g2, st.g2 = pre[j + 3];
-                    st.prev = (T)6 * v + z * st.prev;
+                    st.prev = v + z * st.prev;
                 }
             } else {
-                st.prev = (T)6 * pre[0] / ((T)1 - z);
+                st.prev = pre[0] / ((T)1 - z);
 #pragma unroll
                 for (int j = 0; j < R; j++)
-                    st.prev = (T)6 * pre[j] + z * st.prev;
+                    st.prev = pre[j] + z * st.prev;
             }
             causal_run<T, S, MODE>(line, mid, n, st, w0, w1, w2, w3);
         }
@@ -744,17 +747,17 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     // ---- D: anticausal ----
     if (active) {
         if (seg == 1) {
-            st.next = st.prev * zfin;
+            st.next = st.prev * ((T)6 * zfin);
             st.a1 = st.next, st.a2 = 0, st.a3 = 0;
             if (MODE != 2)
                 line[(n - 1) * S] = st.next;
             anticausal_run<T, S, MODE>(line, n - 2, mid, st, w0, w1, w2, w3);
         } else {
-            st.next = pre[R - 1] * zfin;
+            st.next = pre[R - 1] / ((T)1 - z);  // pre holds q = -z c+:  c+ z / (z - 1) = q / (1 - z)
             st.a1 = st.next, st.a2 = 0, st.a3 = 0;
 #pragma unroll
             for (int j = R - 2; j >= 0; j--) {
-                st.next = z * (st.next - pre[j]);
+                st.next = z * st.next + pre[j];
                 st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
             }
             anticausal_run<T, S, MODE>(line, mid - 1, need_lo, st, w0, w1, w2, w3);

@@ -589,22 +589,26 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     fused::WalkState<T> st;
+    const T z = pole<T>();
     if (lane < Wc && Hc > 1) {
         T *line = reg + lane;
-        st.prev = causal_init<T>([&](int q) { return (T)6 * line[q * LD]; }, Hc, mode);
-        line[0] = st.prev;
+        // causal_run keeps p = c+ / 6 as its state and stores q = -z c+ (srx_fused.hpp, WalkState)
+        const T c0 = causal_init<T>([&](int q) { return (T)6 * line[q * LD]; }, Hc, mode);
+        st.prev = c0 / (T)6;
+        line[0] = -z * c0;
         fused::causal_run<T, LD, 0>(line, 1, Hc, st, (T)0, (T)0, (T)0, (T)0);
-        st.next = anticausal_init<T>(st.prev, line[(Hc - 2) * LD], mode);
+        st.next = anticausal_init<T>((T)6 * st.prev, line[(Hc - 2) * LD] / -z, mode);
         line[(Hc - 1) * LD] = st.next;
         fused::anticausal_run<T, LD, 0>(line, Hc - 2, 0, st, (T)0, (T)0, (T)0, (T)0);
     }
     __syncthreads();
     if (lane < Hc && Wc > 1) {
         T *line = reg + lane * LD;
-        st.prev = causal_init<T>([&](int q) { return (T)6 * line[q]; }, Wc, mode);
-        line[0] = st.prev;
+        const T c0 = causal_init<T>([&](int q) { return (T)6 * line[q]; }, Wc, mode);
+        st.prev = c0 / (T)6;
+        line[0] = -z * c0;
         fused::causal_run<T, 1, 0>(line, 1, Wc, st, (T)0, (T)0, (T)0, (T)0);
-        st.next = anticausal_init<T>(st.prev, line[Wc - 2], mode);
+        st.next = anticausal_init<T>((T)6 * st.prev, line[Wc - 2] / -z, mode);
         line[Wc - 1] = st.next;
         fused::anticausal_run<T, 1, 0>(line, Wc - 2, 0, st, (T)0, (T)0, (T)0, (T)0);
     }
