@@ -491,10 +491,10 @@ __global__ void __launch_bounds__(256)
             hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
     if (ZERO) {
         // c'[p, q] = G[p+1, q+1]
-        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
+        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
         __syncthreads();
     } else {
-        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Wg, pa, qa, ma.RSy, ma.RSx, nr + 3, nc + 3, wave, lane);
+        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa, qa, ma.RSy, ma.RSx, nr + 3, nc + 3, wave, lane);
         __syncthreads();
         SRX_STAMP(1, 1);
         constexpr int RW = TileCfg<T>::R;
