@@ -47,6 +47,9 @@ __device__ unsigned long long srx_dbg_stamps[2][8][40000];  // [kernel][phase][b
 #define SRX_STAMP(K, PH) do { } while (0)
 #endif
 
+#ifndef SRX_FWD_BATCH
+#define SRX_FWD_BATCH 24
+#endif
 using fused::corr7_strip8;
 using fused::Kernel7;
 using fused::TileCfg;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(256)
         const int pb = min(Hp, p0 - ma.Dy + TS + 3 + R), qb = min(Wp, q0 - ma.Dx + TS + 3 + R);
         const int nr = pb - pa, nc = qb - qa;  // > 3 for every tile that holds a contributing pixel
         if (nr > 3 && nc > 3) {
-            fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? 12 : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
+            fused::load_region_pad<T, FR, FR, sizeof(T) == 4 ? SRX_FWD_BATCH : 8>(reg, LD, src, H, W, pa, qa, nr, nc, wave, lane);
             __syncthreads();
             SRX_STAMP(0, 1);
             // rows / columns of Y this tile's far field reads: [p0 - Dy, p0 - Dy + TS) x [q0 - Dx, q0 - Dx + TS); a
