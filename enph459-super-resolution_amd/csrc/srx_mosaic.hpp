@@ -626,11 +626,17 @@ struct FrameOffsets {
 };
 
 template <typename T, int F> struct SaaCfg {
-    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3;  // region edge (odd)
+    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3;  // region edge (odd, <= 128)
     static constexpr int PD = (SR + 12) / F + 6;                                          // LR patch edge bound
-    static constexpr int NPX = (SR * SR + 255) / 256;
+    static constexpr int NT = (SR + 1) / 2;                                               // region rows per wave
+    static constexpr int PPT = (PD * PD + 255) / 256;                                     // patch elements per thread
 };
 
+// One block per T_HR x T_HR output tile; its W-plane region [nrw x ncw] (<= SR^2) is accumulated over the frames in
+// registers and then filtered in LDS.  Per frame: LR patch -> LDS (prefetched into registers during the previous
+// frame); row pass, lane = region column with its x tap in registers, rows wave-uniform; column pass, lane = region
+// ROW with its y tap in registers and the columns unrolled, so the four LR rows a lane combines are four base
+// addresses and every LDS read is base + immediate: 4 reads + 4 fma per output, no index arithmetic.  Two barriers.
 template <typename T, int F>
 __global__ void __launch_bounds__(256)
     k_saa_tile(const T *__restrict__ coef, int N, int h, int w, const AxisTap<T> *__restrict__ zy,
@@ -638,14 +644,15 @@ __global__ void __launch_bounds__(256)
                T *__restrict__ out)
 {
     using C = SaaCfg<T, F>;
-    constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NPX = C::NPX;
-    // LDS: during the frame loop [patch PD*PD | rows PD*SR | zy taps SR | zx taps SR]; afterwards the SR*SR region
+    constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NT = C::NT, PPT = C::PPT;
+    static_assert(SR <= 128, "two 64-lane chunks per axis");
+    // LDS: during the frame loop [patch PD*PD | rows PD*SR]; afterwards the SR*SR region
     constexpr int FRAME_WORDS = PD * PD + PD * SR;
-    constexpr int WORDS = FRAME_WORDS > SR * SR ? FRAME_WORDS : SR * SR;
+    constexpr int WORDS = FRAME_WORDS + NT > SR * SR ? FRAME_WORDS + NT : SR * SR;  // discarded lanes read up to NT words past a row
     __shared__ T lds[WORDS];
-    __shared__ AxisTap<T> ztY[SR], ztX[SR];
     T *patch = lds, *rows = lds + PD * PD, *reg = lds;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = wave & 1, half = wave >> 1;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     int bx, by, b;
     xcd_block(bx, by, b);
@@ -653,60 +660,103 @@ __global__ void __launch_bounds__(256)
     const int pa = max(0, r0 + SRX_NPAD - R), pb = min(Hp, r0 + SRX_NPAD + TS + R);
     const int qa = max(0, c0 + SRX_NPAD - R), qb = min(Wp, c0 + SRX_NPAD + TS + R);
     const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;  // W-plane region = v region + 3
-    T acc[NPX];
+    // row pass: column cc = lane + 64 chunk, LR rows half, half + 2, ...
+    // column pass: region row rr = lane + 64 chunk, columns [NT half, NT half + NT)
+    const int cc = min(lane + 64 * chunk, ncw - 1), rr = min(lane + 64 * chunk, nrw - 1);  // lanes past the region repeat its edge
+    const bool ccok = lane + 64 * chunk < ncw, rrok = lane + 64 * chunk < nrw;
+    const int cb = NT * half;
+    T acc[NT];
 #pragma unroll
-    for (int j = 0; j < NPX; j++)
-        acc[j] = 0;
-    for (int k = 0; k < N; k++) {
+    for (int t = 0; t < NT; t++)
+        acc[t] = 0;
+    // frame k: LR rows/columns its translated window touches (edge clamped = the 12-px pad; mirrored tap indices stay
+    // inside [0, h-1]), from the first / last tap of the window
+    int jy0, jx0, npy, npx;
+    auto geometry = [&](int k) {
         const int oy = fo.oy[k], ox = fo.ox[k];
-        // image rows / columns this frame's translated window covers (edge clamped = the 12-px pad)
         const int y_lo = min(max(pa + oy - SRX_NPAD, 0), H - 1), y_hi = min(max(pa + nrw - 1 + oy - SRX_NPAD, 0), H - 1);
         const int x_lo = min(max(qa + ox - SRX_NPAD, 0), W - 1), x_hi = min(max(qa + ncw - 1 + ox - SRX_NPAD, 0), W - 1);
-        if (tid < nrw)
-            ztY[tid] = zy[min(max(pa + tid + oy - SRX_NPAD, 0), H - 1)];
-        else if (tid >= 128 && tid - 128 < ncw)
-            ztX[tid - 128] = zx[min(max(qa + tid - 128 + ox - SRX_NPAD, 0), W - 1)];
-        // LR patch bounds from the first / last tap tables (mirrored indices stay inside [0, h-1])
         const AxisTap<T> ty0 = zy[y_lo], ty1 = zy[y_hi], tx0 = zx[x_lo], tx1 = zx[x_hi];
-        const int jy0 = min(min(ty0.idx[0], ty0.idx[1]), min(ty0.idx[2], ty0.idx[3]));
-        const int jy1 = max(max(ty1.idx[0], ty1.idx[1]), max(ty1.idx[2], ty1.idx[3]));
-        const int jx0 = min(min(tx0.idx[0], tx0.idx[1]), min(tx0.idx[2], tx0.idx[3]));
-        const int jx1 = max(max(tx1.idx[0], tx1.idx[1]), max(tx1.idx[2], tx1.idx[3]));
-        const int npy = jy1 - jy0 + 1, npx = jx1 - jx0 + 1;  // <= PD
+        jy0 = min(min(ty0.idx[0], ty0.idx[1]), min(ty0.idx[2], ty0.idx[3]));
+        jx0 = min(min(tx0.idx[0], tx0.idx[1]), min(tx0.idx[2], tx0.idx[3]));
+        npy = max(max(ty1.idx[0], ty1.idx[1]), max(ty1.idx[2], ty1.idx[3])) - jy0 + 1;  // <= PD
+        npx = max(max(tx1.idx[0], tx1.idx[1]), max(tx1.idx[2], tx1.idx[3])) - jx0 + 1;
+    };
+    T pre[PPT];
+    AxisTap<T> tX, tY, tYn;
+    auto fetch = [&](int k) {  // this thread's share of frame k's patch (fixed PD-wide mapping, clamped addresses) and its taps
         const T *src = coef + ((size_t)b * N + k) * h * w;
-        for (int idx = tid; idx < npy * npx; idx += 256) {
-            const int py = idx / npx, px = idx - py * npx;
-            patch[py * PD + px] = src[(size_t)(jy0 + py) * w + jx0 + px];
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int idx = tid + 256 * i, py = idx / PD, px = idx - py * PD;
+            pre[i] = src[(size_t)min(jy0 + py, h - 1) * w + min(jx0 + px, w - 1)];
         }
-        __syncthreads();
+        tX = zx[min(max(qa + cc + fo.ox[k] - SRX_NPAD, 0), W - 1)];
+        tYn = zy[min(max(pa + rr + fo.oy[k] - SRX_NPAD, 0), H - 1)];
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int idx = tid + 256 * i, py = idx / PD, px = idx - py * PD;
+            if (py < npy && px < npx)
+                patch[py * PD + px] = pre[i];
+        }
+    };
+    geometry(0);
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (int k = 0; k < N; k++) {
+        tY = tYn;
         // row pass: rows[py][cc] = sum_j zx[x(cc)].w[j] * patch[py][idx[j]]
-        for (int idx = tid; idx < npy * ncw; idx += 256) {
-            const int py = idx / ncw, cc = idx - py * ncw;
-            const AxisTap<T> t = ztX[cc];
-            const T *pr = patch + py * PD - jx0;
-            rows[py * SR + cc] = t.w[0] * pr[t.idx[0]] + t.w[1] * pr[t.idx[1]] + t.w[2] * pr[t.idx[2]] + t.w[3] * pr[t.idx[3]];
-        }
-        __syncthreads();
-        // column pass, accumulated over frames: up_k(y(rr), x(cc)) = sum_i zy[y].w[i] * rows[idx[i]][cc]
+        {
+            const T *p0 = patch + tX.idx[0] - jx0, *p1 = patch + tX.idx[1] - jx0, *p2 = patch + tX.idx[2] - jx0,
+                    *p3 = patch + tX.idx[3] - jx0;
+            // all reads of the patch first: rows and patch share the LDS array, so hipcc would otherwise order each
+            // row's store before the next row's loads (one LDS round trip per row)
+            T v[(PD + 1) / 2];
 #pragma unroll
-        for (int j = 0; j < NPX; j++) {
-            const int idx = min(tid + 256 * j, nrw * ncw - 1);  // clamped duplicate for the ragged tail; dropped below
-            const int rr = idx / ncw, cc = idx - rr * ncw;
-            const AxisTap<T> t = ztY[rr];
-            const T *pc = rows + cc - jy0 * SR;
-            acc[j] += t.w[0] * pc[t.idx[0] * SR] + t.w[1] * pc[t.idx[1] * SR] + t.w[2] * pc[t.idx[2] * SR] +
-                      t.w[3] * pc[t.idx[3] * SR];
+            for (int t = 0; t < (PD + 1) / 2; t++) {
+                const int py = min(half + 2 * t, PD - 1);
+                v[t] = tX.w[0] * p0[py * PD] + tX.w[1] * p1[py * PD] + tX.w[2] * p2[py * PD] + tX.w[3] * p3[py * PD];
+                if (t % 4 == 3)  // as in the column pass below: 16 reads in flight
+                    asm volatile("" : "+v"(v[t - 3]), "+v"(v[t - 2]), "+v"(v[t - 1]), "+v"(v[t])::"memory");
+            }
+#pragma unroll
+            for (int t = 0; t < (PD + 1) / 2; t++) {
+                const int py = half + 2 * t;
+                if (py < npy && ccok)
+                    rows[py * SR + cc] = v[t];
+            }
         }
+        const int cjy0 = jy0;
+        __syncthreads();
+        if (k + 1 < N) {  // next frame's patch and taps: in flight during the column pass
+            geometry(k + 1);
+            fetch(k + 1);
+        }
+        // column pass, accumulated over frames: up_k(y(rr), x) = sum_i zy[y].w[i] * rows[idx[i]][x]
+        {
+            const T *q0 = rows + (tY.idx[0] - cjy0) * SR + cb, *q1 = rows + (tY.idx[1] - cjy0) * SR + cb,
+                    *q2 = rows + (tY.idx[2] - cjy0) * SR + cb, *q3 = rows + (tY.idx[3] - cjy0) * SR + cb;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                acc[t] += tY.w[0] * q0[t] + tY.w[1] * q1[t] + tY.w[2] * q2[t] + tY.w[3] * q3[t];
+                // pin the accumulator updates in place, 8 outputs (32 reads in flight) at a time: left alone, instruction
+                // selection sinks all NT x 4 fmas below all NT x 4 LDS reads (256 VGPRs, 2 blocks per CU, AGPR spills)
+                if (t % 8 == 7)
+                    asm volatile("" : "+v"(acc[t - 7]), "+v"(acc[t - 6]), "+v"(acc[t - 5]), "+v"(acc[t - 4]), "+v"(acc[t - 3]),
+                                 "+v"(acc[t - 2]), "+v"(acc[t - 1]), "+v"(acc[t])::"memory");
+            }
+        }
+        if (k + 1 < N)
+            stash();  // the row pass of this frame is done with the patch
         __syncthreads();
     }
 #pragma unroll
-    for (int j = 0; j < NPX; j++) {
-        const int idx = tid + 256 * j;
-        if (idx < nrw * ncw) {
-            const int rr = idx / ncw, cc = idx - rr * ncw;
-            reg[rr * LD + cc] = acc[j];
-        }
-    }
+    for (int t = 0; t < NT; t++)
+        if (rrok && cb + t < ncw)
+            reg[rr * LD + cb + t] = acc[t];
     __syncthreads();
     const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
     fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid, r_lo);
