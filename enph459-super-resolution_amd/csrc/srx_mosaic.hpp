@@ -151,8 +151,9 @@ __device__ __forceinline__ int near_index(int p, int q, int Wg, int PBy, int PBx
 // at their own (unreplicated) position, the ones the MSE trace counts.  V = sum over pixels of the within-pixel
 // scatter sum_k (l_k - mean)^2 of the counted samples (constant over the iterations; non-zero only where two
 // frames share a phase)
-#define MOSAIC_IB 8  // batch items per thread: the tap tables are per (frame, coordinate), shared by all items
-template <typename T>
+// MOSAIC_IB batch items per thread: the tap tables are per (frame, coordinate), shared by all items (8 for batches, 1 for
+// a single full frame)
+template <typename T, int MOSAIC_IB>
 __global__ void __launch_bounds__(256)
     k_mosaic_build(const T *__restrict__ lr, int B, int N, int h, int w, const MTap *__restrict__ tabY,
                    const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
@@ -171,9 +172,13 @@ __global__ void __launch_bounds__(256)
         for (int i = 0; i < MOSAIC_IB; i++)
             M[i] = S1[i] = S2[i] = 0.0;
         int C = 0, Cu = 0;
+        const int pu = __builtin_amdgcn_readfirstlane(p);  // block (64, 4): one row per wave
         for (int k = 0; k < N; k++) {
-            const MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
-            if (ty.i < 0 || tx.i < 0)
+            const MTap ty = tabY[(size_t)k * Hg + pu];  // wave-uniform (a scalar load): most frames miss this row entirely
+            if (ty.i < 0)
+                continue;
+            const MTap tx = tabX[(size_t)k * Wg + q];
+            if (tx.i < 0)
                 continue;
             const bool counted = ty.rho == p - Dy && tx.rho == q - Dx;
             const T *src = lr + (size_t)(k * h + ty.i) * w + tx.i;
@@ -836,8 +841,12 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     SRX_CHECK_LAUNCH();
     if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
-    SRX_LAUNCH(KID_MOSAIC_BUILD, k_mosaic_build<T>, dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, MOSAIC_IB)), dim3(64, 4), 0, st, lr, B, N, h, w, tabY,
-               tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+    if (B >= 8)
+        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h, w,
+                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+    else
+        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w, tabY,
+                   tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
     hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
