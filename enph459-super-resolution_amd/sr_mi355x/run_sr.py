@@ -20,6 +20,9 @@ def main(argv=None):
     ap.add_argument("--data-dir", required=True)
     ap.add_argument("--output-dir", required=True)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--metrics", action="store_true",
+                    help="mono_cal_target only: also write metrics.json (slanted-edge MTF50/MTF10, bar contrast: the "
+                         "summary of the reference's analysis.ipynb) next to the PNGs")
     args = ap.parse_args(argv)
     api.set_precision(args.precision)
     if args.psf == "measured":
@@ -35,7 +38,10 @@ def main(argv=None):
     t0 = time.time()
     for i, s in enumerate(sessions, 1):
         print(f"\n[{i}/{len(sessions)}] {os.path.basename(s)}")
-        session.process_session(s, psf, args.output_dir, kind=args.kind)
+        written = session.process_session(s, psf, args.output_dir, kind=args.kind)
+        if args.metrics and args.kind == "mono_cal_target":
+            for out_dir in written:
+                session.write_metrics(out_dir)
     print(f"\nAll sessions done in {(time.time() - t0) / 60:.1f} min")
 
 

@@ -208,6 +208,19 @@ def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None
     return written
 
 
+def write_metrics(out_dir, factor=UPSAMPLE_FACTOR):
+    """metrics.json for one mono_cal_target output directory: the reference's notebook summary (analysis.ipynb cells
+    3-10) computed from the uint8 PNGs just written, as the notebook does."""
+    import numpy as np
+    from PIL import Image
+    from . import metrics
+    imgs = {n: np.array(Image.open(os.path.join(out_dir, n + ".png")), dtype=np.float64) for n in ("native_2x", "SAA", "SAA_IBP")}
+    rep = metrics.cal_target_report(imgs, factor=factor)
+    with open(os.path.join(out_dir, "metrics.json"), "w") as fp:
+        json.dump(rep, fp, indent=2)
+    return rep
+
+
 def discover_sessions(data_dir, kind):
     """main()'s session discovery (mono_cal_target/run_sr.py:338-343 and the corner-layout variants)."""
     out = []
