@@ -56,7 +56,7 @@ def kernel_model_bytes(name, B, N, h, w, f, eb):
     H, W = h * f, w * f
     hw, pad, lrn = B * H * W * eb, B * (H + 24) * (W + 24) * eb, B * N * h * w * eb
     return {
-        "k_blur_pad": hw + pad,                 # read hr, write padded blur
+        "k_blur_pad": 2 * hw,                   # read hr, write the blurred plane (its pad is applied by the tile loaders)
         "k_prefilter_axis0": 2 * pad,           # read + write the padded plane
         "k_prefilter_axis1": 2 * pad,
         "k_fwd_residual": pad + 2 * lrn,        # read coefficients + LR frames, write residuals
@@ -227,6 +227,30 @@ def main():
                 if tj.get("workload") == f"C2:B={B}" and dom in tj.get("kernels", {}):
                     roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
 
+    # ---- secondary figures: shift_and_add alone, and the same step from / to HOST buffers ----
+    extras = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            S.shift_and_add_batched(lr, shifts, f, precision=prec)
+        torch.cuda.synchronize()
+        t_saa = (time.perf_counter() - t1) / 3
+        lr_host = lr.cpu().pin_memory()
+        hr_host = torch.empty((B, H, W), dtype=lr.dtype).pin_memory()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lr_d = lr_host.cuda(non_blocking=True)
+        saa_d = S.shift_and_add_batched(lr_d, shifts, f, precision=prec)
+        hr_d, _ = S.ibp_batched(lr_d, shifts, psf, saa_d, f, n_iter, step, precision=prec, out=saa_d)
+        hr_host.copy_(hr_d, non_blocking=True)
+        torch.cuda.synchronize()
+        t_host = time.perf_counter() - t1
+        extras = {"saa_only_hr_mp_per_s": round(B * H * W / 1e6 / t_saa, 1), "saa_only_ms": round(t_saa * 1e3, 3),
+                  "host_buffers_hr_mp_per_s": round(B * H * W / 1e6 / t_host, 1), "host_buffers_ms": round(t_host * 1e3, 3),
+                  "host_buffers_note": "pinned host LR in, pinned host HR out, H2D + step + D2H on one stream; never the headline value"}
+        del lr_host, hr_host, lr_d, saa_d, hr_d
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, hr_cpu, lr_cpu, it_cpu = cpu_baseline(synth, f, lr_hw, shifts, psf, n_iter, step)
@@ -245,7 +269,7 @@ def main():
                        "patches_per_gpu": B, "global_patches": world * B, "factor": f, "frames": N, "lr_patch": [h, w],
                        "n_iter": n_iter, "path": path, "parallelism": f"patch-sharded x{world}, no collective"},
             "hr_mp_iter_per_s": round(value * n_iter, 1), "sane": sane,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "secondary": extras, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
