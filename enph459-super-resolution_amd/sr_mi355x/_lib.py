@@ -75,6 +75,10 @@ def load():
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
                            "(sr_mi355x has no CPU fallback)")
+    # torch first: PyTorch-ROCm ships its own libamdhip64 and libsrx.so must bind to THAT runtime (the one that owns the
+    # caller's device pointers and streams).  Loaded the other way round, libsrx.so pulls in /opt/rocm's copy, the process
+    # holds two HIP runtimes and every launch on a torch pointer fails with hipErrorInvalidValue.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(SO_PATH)
     for name, (res, args) in _PLAIN.items():
         fn = getattr(lib, name)
