@@ -220,6 +220,16 @@ template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_r
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
 
+template <typename T> __device__ __forceinline__ void buf_store(T v, __amdgpu_buffer_rsrc_t rs, int voff, int soff);
+template <> __device__ __forceinline__ void buf_store<float>(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_store<double>(double v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rs, voff, soff, 0);
+}
 template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const T *plane, size_t elems)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, (int)(elems * sizeof(T)), 0x00020000);

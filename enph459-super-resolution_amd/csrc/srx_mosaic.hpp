@@ -491,12 +491,17 @@ __global__ void __launch_bounds__(256)
     const int nr = pb - pa, nc = qb - qa;
     SRX_STAMP(1, 0);
     // this thread's TS*TS/256 hr pixels, fetched up front (clamped addresses): latency hides behind the tile work
+    // (buffer loads / stores: the row part of an address is wave-uniform -> SGPR offset, no per-element address arithmetic)
     T hv[TS / 32][8];
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rs_in = fused::plane_rsrc(hr_in + (size_t)b * H * W, (size_t)H * W);
+    const __amdgpu_buffer_rsrc_t rs_out = fused::plane_rsrc(hr_out + (size_t)b * H * W, (size_t)H * W);
+    const int hcol = min(c0 + lane, W - 1) * (int)sizeof(T);
 #pragma unroll
     for (int half = 0; half < TS / 32; half++)
 #pragma unroll
         for (int o = 0; o < 8; o++)
-            hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
+            hv[half][o] = fused::buf_load<T>(rs_in, hcol, min(r0 + half * 32 + uw * 8 + o, H - 1) * W * (int)sizeof(T));
     if (ZERO) {
         // c'[p, q] = G[p+1, q+1]
         fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
@@ -539,7 +544,7 @@ __global__ void __launch_bounds__(256)
     SRX_STAMP(1, 4);
     const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
     const int c = c0 + lane;
-    const size_t base = (size_t)b * H * W;
+    const T sn = step / n;  // hr + step * corr / N evaluated as hr + corr * (step / N): one rounding of the factor (<= 1 ulp)
 #pragma unroll
     for (int half = 0; half < TS / 32; half++) {
         if (lane < TS && !(dbg & 64)) {
@@ -547,11 +552,10 @@ __global__ void __launch_bounds__(256)
             corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
 #pragma unroll
             for (int o = 0; o < 8; o++) {
-                const int r = r0 + half * 32 + wave * 8 + o;
+                const int r = r0 + half * 32 + uw * 8 + o;
                 if (r < H && c < W) {
-                    const size_t i = base + (size_t)r * W + c;
-                    T v = hv[half][o] + step * a8[o] / n;
-                    hr_out[i] = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
+                    const T v = hv[half][o] + a8[o] * sn;
+                    fused::buf_store<T>(v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v), rs_out, hcol, r * W * (int)sizeof(T));
                 }
             }
         }
