@@ -313,28 +313,30 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     int bx, by, bz;
     xcd_block(bx, by, bz);
     const int c0 = bx * SRX_BT_W, r0 = by * SRX_BT_H;
-    const T *src = hr + (size_t)bz * H * W;
+    const int uy = __builtin_amdgcn_readfirstlane(ty);  // block (64, 4): ty is the wave
     {
-        // (32+6) x (64+6) source tile, zero outside the image: all loads first (clamped addresses), then the stores
+        // (32+6) x (64+6) source tile, zero outside the image: all loads first (clamped addresses; buffer loads with the
+        // row in an SGPR offset), then the stores
         constexpr int RPW = (SRX_BT_H + 6 + 3) / 4;  // 10 rows per wave
+        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(hr + (size_t)bz * H * W, (size_t)H * W);
+        const int ca = c0 - 3 + tx, cb = c0 + 61 + (tx & 7);  // columns 0..63 and 64..69 of the tile
+        const int va = min(max(ca, 0), W - 1) * (int)sizeof(T), vb = min(max(cb, 0), W - 1) * (int)sizeof(T);
+        const bool ina = ca >= 0 && ca < W, inb = cb >= 0 && cb < W;
         T v[RPW][2];
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
-            const int r = min(max(r0 - 3 + ty + 4 * j, 0), H - 1);
-            v[j][0] = src[(size_t)r * W + min(max(c0 - 3 + tx, 0), W - 1)];
-            v[j][1] = src[(size_t)r * W + min(max(c0 + 61 + (tx & 7), 0), W - 1)];  // columns 64..69 of the tile
+            const int so = min(max(r0 - 3 + uy + 4 * j, 0), H - 1) * W * (int)sizeof(T);
+            v[j][0] = buf_load<T>(rs, va, so);
+            v[j][1] = buf_load<T>(rs, vb, so);
         }
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
-            const int sr = ty + 4 * j, r = r0 - 3 + sr;
+            const int sr = uy + 4 * j, r = r0 - 3 + sr;
             if (sr < SRX_BT_H + 6) {
                 const bool rin = r >= 0 && r < H;
-                const int c = c0 - 3 + tx;
-                tile[sr * SRX_BT_LDW + tx] = (rin && c >= 0 && c < W) ? v[j][0] : (T)0;
-                if (tx < 6) {
-                    const int c2 = c0 + 61 + tx;
-                    tile[sr * SRX_BT_LDW + 64 + tx] = (rin && c2 >= 0 && c2 < W) ? v[j][1] : (T)0;
-                }
+                tile[sr * SRX_BT_LDW + tx] = (rin && ina) ? v[j][0] : (T)0;
+                if (tx < 6)
+                    tile[sr * SRX_BT_LDW + 64 + tx] = (rin && inb) ? v[j][1] : (T)0;
             }
         }
     }
@@ -345,12 +347,12 @@ __global__ void __launch_bounds__(256) k_blur_pad(const T *__restrict__ hr, int 
     if (c >= W)
         return;
     if (!PAD) {  // plain [H, W] plane; consumers read it through load_region_pad
-        T *out = bpad + (size_t)bz * H * W;
+        const __amdgpu_buffer_rsrc_t ro = plane_rsrc(bpad + (size_t)bz * H * W, (size_t)H * W);
 #pragma unroll
         for (int o = 0; o < 8; o++) {
-            const int r = r0 + ty * 8 + o;
+            const int r = r0 + uy * 8 + o;
             if (r < H)
-                out[(size_t)r * W + c] = acc[o];
+                buf_store<T>(acc[o], ro, c * (int)sizeof(T), r * W * (int)sizeof(T));
         }
         return;
     }
