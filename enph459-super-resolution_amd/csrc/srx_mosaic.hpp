@@ -302,12 +302,26 @@ __global__ void __launch_bounds__(256)
     // latency hides behind the tile's prefilter
     constexpr int NPX = TS * TS / 256;
     T Cv[NPX], Mv[NPX];
+    const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(Cg, (size_t)Hg * Wg);
+    const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(Mg + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+    const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(G + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (TS == 64) {  // a pixel row per wave: the row is an SGPR offset of a buffer load, no per-element addressing
+        const int vc = min(q0 + lane, Wg - 1) * (int)sizeof(T);
 #pragma unroll
-    for (int j = 0; j < NPX; j++) {
-        const int idx = tid + 256 * j;
-        const size_t gi = (size_t)min(p0 + idx / TS, Hg - 1) * Wg + min(q0 + idx % TS, Wg - 1);
-        Cv[j] = Cg[gi];
-        Mv[j] = Mg[(size_t)b * Hg * Wg + gi];
+        for (int j = 0; j < NPX; j++) {
+            const int so = min(p0 + uwave + 4 * j, Hg - 1) * Wg * (int)sizeof(T);
+            Cv[j] = fused::buf_load<T>(rsC, vc, so);
+            Mv[j] = fused::buf_load<T>(rsM, vc, so);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const int idx = tid + 256 * j;
+            const size_t gi = (size_t)min(p0 + idx / TS, Hg - 1) * Wg + min(q0 + idx % TS, Wg - 1);
+            Cv[j] = Cg[gi];
+            Mv[j] = Mg[(size_t)b * Hg * Wg + gi];
+        }
     }
     SRX_STAMP(0, 0);
     int pa = 0, qa = 0;
@@ -398,10 +412,12 @@ __global__ void __launch_bounds__(256)
         // interior tile: every pixel is far field and inside the plane
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
-            const int pg = p0 + prow + j * RPJ;
             const T g = Cv[j] > (T)0 ? Mv[j] - Cv[j] * Yv[j] : (T)0;  // Yv may be LDS garbage where C = 0
             sqt += g * g * rcp_count(Cv[j]);
-            Gp[pg * Wg] = g;
+            if constexpr (TS == 64)
+                fused::buf_store<T>(g, rsG, qg * (int)sizeof(T), (p0 + uwave + 4 * j) * Wg * (int)sizeof(T));
+            else
+                Gp[(p0 + prow + j * RPJ) * Wg] = g;
         }
     } else {
 #pragma unroll
