@@ -533,30 +533,7 @@ __global__ void __launch_bounds__(256)
         fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid, c0 + 9 - qa);
         SRX_STAMP(1, 3);
     }
-    // B' sees zeros outside the image (fftconvolve 'same' on the H x W array), not the pad.  Of the window
-    // [r0-3, r0+TS+3) x [c0-3, c0+TS+3) only the three rows/columns just outside an image edge are ever read by
-    // a pixel this tile writes: 12 strips of TS+6 cells.
-    if (r0 == 0 || c0 == 0 || r0 + TS + 3 > H || c0 + TS + 3 > W) {
-        constexpr int WN = TS + 6;
-        T *win0 = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
-        const int wrb = H - r0 + 3, wcb = W - c0 + 3;         // window row / column of image row H / column W
-        for (int idx = tid; idx < 12 * WN; idx += 256) {
-            const int strip = idx / WN, pos = idx - strip * WN, o = strip % 3;
-            int wr, wc;
-            bool on;
-            if (strip < 3)
-                wr = o, wc = pos, on = r0 == 0;
-            else if (strip < 6)
-                wr = wrb + o, wc = pos, on = wr < WN;
-            else if (strip < 9)
-                wr = pos, wc = o, on = c0 == 0;
-            else
-                wr = pos, wc = wcb + o, on = wc < WN;
-            if (on)
-                win0[wr * LD + wc] = 0;
-        }
-        __syncthreads();
-    }
+    fused::zero_outside_image<T, TS, LD>(reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa), r0, c0, H, W, tid);
     SRX_STAMP(1, 4);
     const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
     const int c = c0 + lane;
