@@ -142,7 +142,7 @@ template <> struct Warmup<double> { static constexpr int n = 40; };
 
 // axis 0 (down the columns): one thread per (column, chunk, item); lanes walk adjacent columns -> coalesced.
 template <typename T>
-__global__ void __launch_bounds__(64) k_prefilter_axis0(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode)
+__global__ void __launch_bounds__(64) k_prefilter_axis0(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode, int chunk)
 {
     constexpr int WU = Warmup<T>::n;
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) k_prefilter_axis0(const T *__restrict__ sr
     const size_t s = Wc;
     const T *src = src_ + (size_t)blockIdx.z * Hc * Wc + c;
     T *dst = dst_ + (size_t)blockIdx.z * Hc * Wc + c;
-    const int start = blockIdx.y * SRX_PF_CHUNK, end = min(start + SRX_PF_CHUNK, Hc);
+    const int start = blockIdx.y * chunk, end = min(start + chunk, Hc);
     if (Hc <= 1) {
         if (start == 0)
             dst[0] = src[0];
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64) k_prefilter_axis0(const T *__restrict__ sr
 // one tail tile after it play the role of WU above.
 #define SRX_PF_SEG 8
 template <typename T>
-__global__ void __launch_bounds__(64) k_prefilter_axis1(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode)
+__global__ void __launch_bounds__(64) k_prefilter_axis1(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode, int seg)
 {
     __shared__ T tile[64][65];
     __shared__ T tailt[64][65];
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64) k_prefilter_axis1(const T *__restrict__ sr
     const T *src = src_ + (size_t)blockIdx.z * Hc * Wc + (size_t)r0 * Wc;
     T *dst = dst_ + (size_t)blockIdx.z * Hc * Wc + (size_t)r0 * Wc;
     const int ntile = cdiv(Wc, 64);
-    const int t0 = blockIdx.y * SRX_PF_SEG, t1 = min(t0 + SRX_PF_SEG, ntile);  // own tiles [t0, t1)
+    const int t0 = blockIdx.y * seg, t1 = min(t0 + seg, ntile);  // own tiles [t0, t1)
     if (Wc <= 1) {
         if (t0 == 0 && lane < rows)
             dst[(size_t)lane * Wc] = src[(size_t)lane * Wc];
@@ -314,10 +314,18 @@ template <typename T> static int prefilter2d(T *a, T *scratch, int B, int Hc, in
 {
     if (B > 65535)
         return SRX_E_UNSUPPORTED;
-    SRX_LAUNCH(KID_PREFILTER_AXIS0, k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), cdiv(Hc, SRX_PF_CHUNK), B), dim3(64), 0, st,
-               a, scratch, Hc, Wc, mode);
-    SRX_LAUNCH(KID_PREFILTER_AXIS1, k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), cdiv(cdiv(Wc, 64), SRX_PF_SEG), B),
-               dim3(64), 0, st, scratch, a, Hc, Wc, mode);
+    // lines per thread / tiles per wave sized so that a small batch of large frames still fills the chip (~1024 SIMDs x a
+    // few waves): a chunk costs WU warm-up samples at each end, a segment one warm-up and one tail tile
+    int chunk = SRX_PF_CHUNK;
+    while (chunk > 32 && (long)cdiv(Wc, 64) * cdiv(Hc, chunk) * B < 4096)
+        chunk >>= 1;
+    int seg = SRX_PF_SEG;
+    while (seg > 1 && (long)cdiv(Hc, 64) * cdiv(cdiv(Wc, 64), seg) * B < 4096)
+        seg >>= 1;
+    SRX_LAUNCH(KID_PREFILTER_AXIS0, k_prefilter_axis0<T>, dim3(cdiv(Wc, 64), cdiv(Hc, chunk), B), dim3(64), 0, st, a, scratch, Hc, Wc,
+               mode, chunk);
+    SRX_LAUNCH(KID_PREFILTER_AXIS1, k_prefilter_axis1<T>, dim3(cdiv(Hc, 64), cdiv(cdiv(Wc, 64), seg), B), dim3(64), 0, st, scratch,
+               a, Hc, Wc, mode, seg);
     return SRX_OK;
 }
 
