@@ -151,74 +151,96 @@ __device__ __forceinline__ int near_index(int p, int q, int Wg, int PBy, int PBx
 // at their own (unreplicated) position, the ones the MSE trace counts.  V = sum over pixels of the within-pixel
 // scatter sum_k (l_k - mean)^2 of the counted samples (constant over the iterations; non-zero only where two
 // frames share a phase)
-// MOSAIC_IB batch items per thread: the tap tables are per (frame, coordinate), shared by all items (8 for batches, 1 for
-// a single full frame)
-template <typename T, int MOSAIC_IB>
+// A thread owns PXT pixels of one row (columns q, q + 64, ...) for IB batch items: the tap tables are per (frame,
+// coordinate) and shared by all items, the row tap is wave-uniform (a scalar load; most frames miss a given row entirely),
+// and the PXT x IB sample loads of a frame are independent and issued together.  (8 items x 1 pixel for batches of patches,
+// 1 item x 4 pixels for a single full frame.)
+template <typename T, int IB, int PXT>
 __global__ void __launch_bounds__(256)
     k_mosaic_build(const T *__restrict__ lr, int B, int N, int h, int w, const MTap *__restrict__ tabY,
                    const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
                    T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot)
 {
-    __shared__ double part[4][MOSAIC_IB];
-    const int q = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b0 = blockIdx.z * MOSAIC_IB;
+    __shared__ double part[4][IB];
+    const int q0 = blockIdx.x * 64 * PXT + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b0 = blockIdx.z * IB;
+    const int pu = __builtin_amdgcn_readfirstlane(p);  // block (64, 4): one row per wave
     const size_t item = (size_t)N * h * w;
-    double var[MOSAIC_IB];
+    double var[IB];
 #pragma unroll
-    for (int i = 0; i < MOSAIC_IB; i++)
+    for (int i = 0; i < IB; i++)
         var[i] = 0.0;
-    if (p < Hg && q < Wg) {
-        double M[MOSAIC_IB], S1[MOSAIC_IB], S2[MOSAIC_IB];  // S1, S2: over the counted samples
+    if (pu < Hg) {
+        double M[PXT][IB], S1[PXT][IB], S2[PXT][IB];  // S1, S2: over the counted samples
+        int C[PXT], Cu[PXT];
 #pragma unroll
-        for (int i = 0; i < MOSAIC_IB; i++)
-            M[i] = S1[i] = S2[i] = 0.0;
-        int C = 0, Cu = 0;
-        const int pu = __builtin_amdgcn_readfirstlane(p);  // block (64, 4): one row per wave
+        for (int c = 0; c < PXT; c++) {
+            C[c] = Cu[c] = 0;
+#pragma unroll
+            for (int i = 0; i < IB; i++)
+                M[c][i] = S1[c][i] = S2[c][i] = 0.0;
+        }
         for (int k = 0; k < N; k++) {
-            const MTap ty = tabY[(size_t)k * Hg + pu];  // wave-uniform (a scalar load): most frames miss this row entirely
+            const MTap ty = tabY[(size_t)k * Hg + pu];
             if (ty.i < 0)
                 continue;
-            const MTap tx = tabX[(size_t)k * Wg + q];
-            if (tx.i < 0)
-                continue;
-            const bool counted = ty.rho == p - Dy && tx.rho == q - Dx;
-            const T *src = lr + (size_t)(k * h + ty.i) * w + tx.i;
-            T l[MOSAIC_IB];
+            MTap tx[PXT];
 #pragma unroll
-            for (int i = 0; i < MOSAIC_IB; i++)
-                l[i] = src[(size_t)min(b0 + i, B - 1) * item];  // clamped duplicate for a ragged last group; dropped below
-            C++;
-            Cu += counted ? 1 : 0;
+            for (int c = 0; c < PXT; c++)
+                tx[c] = tabX[(size_t)k * Wg + min(q0 + 64 * c, Wg - 1)];
+            if (PXT == 1 && tx[0].i < 0)
+                continue;  // one pixel per thread: skipping beats issuing IB dropped loads
+            T l[PXT][IB];
 #pragma unroll
-            for (int i = 0; i < MOSAIC_IB; i++) {
-                const double lv = (double)l[i];
-                M[i] += lv;
-                if (counted)
-                    S1[i] += lv, S2[i] += lv * lv;
+            for (int c = 0; c < PXT; c++) {
+                const T *src = lr + (size_t)(k * h + ty.i) * w + max(tx[c].i, 0);  // a miss reads column 0 and is dropped
+#pragma unroll
+                for (int i = 0; i < IB; i++)
+                    l[c][i] = src[(size_t)min(b0 + i, B - 1) * item];  // clamped duplicate for a ragged last group
+            }
+#pragma unroll
+            for (int c = 0; c < PXT; c++) {
+                const bool hit = tx[c].i >= 0;
+                const bool counted = hit && ty.rho == pu - Dy && tx[c].rho == q0 + 64 * c - Dx;
+                C[c] += hit ? 1 : 0;
+                Cu[c] += counted ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < IB; i++) {
+                    const double lv = (double)l[c][i];
+                    M[c][i] += hit ? lv : 0.0;
+                    S1[c][i] += counted ? lv : 0.0;
+                    S2[c][i] += counted ? lv * lv : 0.0;
+                }
             }
         }
-        if (b0 == 0)
-            Cg[(size_t)p * Wg + q] = (T)C;
-        const bool nearpx = p < PBy || q < PBx;
-        const int ni = nearpx ? near_index(p, q, Wg, PBy, PBx) : 0;
 #pragma unroll
-        for (int i = 0; i < MOSAIC_IB; i++) {
-            if (b0 + i >= B)
+        for (int c = 0; c < PXT; c++) {
+            const int q = q0 + 64 * c;
+            if (q >= Wg)
                 continue;
-            Mg[((size_t)(b0 + i) * Hg + p) * Wg + q] = (T)M[i];
-            if (nearpx)
-                Mu[(size_t)(b0 + i) * NB + ni] = (T)S1[i];
-            if (Cu > 1)
-                var[i] = S2[i] - S1[i] * S1[i] / (double)Cu;
+            if (b0 == 0)
+                Cg[(size_t)pu * Wg + q] = (T)C[c];
+            const bool nearpx = pu < PBy || q < PBx;
+            const int ni = nearpx ? near_index(pu, q, Wg, PBy, PBx) : 0;
+#pragma unroll
+            for (int i = 0; i < IB; i++) {
+                if (b0 + i >= B)
+                    continue;
+                Mg[((size_t)(b0 + i) * Hg + pu) * Wg + q] = (T)M[c][i];
+                if (nearpx)
+                    Mu[(size_t)(b0 + i) * NB + ni] = (T)S1[c][i];
+                if (Cu[c] > 1)
+                    var[i] += S2[c][i] - S1[c][i] * S1[c][i] / (double)Cu[c];
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MOSAIC_IB; i++) {
+    for (int i = 0; i < IB; i++) {
         const double v = wave_sum(var[i]);
         if (threadIdx.x == 0)
             part[threadIdx.y][i] = v;
     }
     __syncthreads();
-    if (threadIdx.y == 0 && threadIdx.x < MOSAIC_IB && b0 + threadIdx.x < B) {
+    if (threadIdx.y == 0 && threadIdx.x < IB && b0 + threadIdx.x < B) {
         const int i = threadIdx.x;
         const double s = part[0][i] + part[1][i] + part[2][i] + part[3][i];
         if (s != 0.0)
@@ -839,11 +861,11 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
     if (B >= 8)
-        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h, w,
-                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h,
+                   w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
     else
-        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w, tabY,
-                   tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1, 4>), dim3(cdiv(Wg, 256), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w,
+                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
     hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
