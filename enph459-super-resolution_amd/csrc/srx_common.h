@@ -154,6 +154,25 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
     bz = (int)(id / (gx * gy));
 }
 
+// MSE trace without atomics.  Every block of a forward kernel stores its partial sum at epart[item * nblk + tile] (tile =
+// by * gridDim.x + bx of the remapped block); the block (0, 0) of that item in the following backward kernel adds them up
+// in a fixed order: deterministic, and nothing serialises when ONE large frame has thousands of tiles (3185 double
+// atomics into one address cost 35 us of a 51 us kernel).  `part4`: 4 doubles of LDS.  Block-uniform call; has a barrier.
+__device__ __forceinline__ void err_trace_reduce(const double *__restrict__ epart, int nblk, int item, double base,
+                                                 double *__restrict__ out, int tid, double *part4)
+{
+    double s = 0.0;
+    for (int i = tid; i < nblk; i += 256)
+        s += epart[(size_t)item * nblk + i];
+    s = wave_sum(s);
+    if ((tid & 63) == 0)
+        part4[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0)
+        *out = base + ((part4[0] + part4[1]) + (part4[2] + part4[3]));
+    __syncthreads();
+}
+
 // cubic B-spline weights for fractional offset t in [0, 1), computed as scipy does (ni_splines.c)
 __device__ __forceinline__ void bspline3_weights(double t, double w[4])
 {

@@ -823,7 +823,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     k_fwd_tile(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ lr, int h, int w, int f,
                FrameSet<T> fs, int omin_y, int omax_y, int omin_x, int omax_x, int th, int tw, T *__restrict__ err,
-               double *__restrict__ errors, int errors_stride, double scale)
+               double *__restrict__ epart, double scale)
 {
     constexpr int R = TileCfg<T>::R, FR = TileCfg<T>::T_HR + 12 + 2 * R, LD = FR + 1;
     __shared__ T reg[FR * LD];
@@ -870,8 +870,8 @@ __global__ void __launch_bounds__(256)
     if (lane == 0)
         part[wave] = sq;
     __syncthreads();
-    if (tid == 0 && errors)
-        atomicAdd(&errors[(size_t)b * errors_stride], (part[0] + part[1] + part[2] + part[3]) * scale);
+    if (tid == 0 && epart)  // this tile's share of the MSE trace; summed by k_bwd_tile (err_trace_reduce)
+        epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = (part[0] + part[1] + part[2] + part[3]) * scale;
 }
 
 // Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= L LR samples
@@ -975,7 +975,8 @@ template <typename T, int F, bool SEP>
 __global__ void __launch_bounds__(256)
     k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, BwdCfg<T, F>::L> *__restrict__ tyT,
                const LTap<T, BwdCfg<T, F>::L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n,
-               const T *__restrict__ hr_in, T *__restrict__ hr_out)
+               const T *__restrict__ hr_in, T *__restrict__ hr_out, const double *__restrict__ epart, int nblk,
+               double *__restrict__ errors, int errors_stride)
 {
     using C = BwdCfg<T, F>;
     constexpr int R = C::R, TS = C::TS, BR = C::BR, LD = BR + 1, L = C::L, KS = C::KS;
@@ -984,6 +985,10 @@ __global__ void __launch_bounds__(256)
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     int bx, by, b;
     xcd_block(bx, by, b);
+    if (errors && bx == 0 && by == 0) {  // MSE trace of this iteration from the forward kernel's per-tile sums
+        __shared__ double part4[4];
+        err_trace_reduce(epart, nblk, b, 0.0, errors + (size_t)b * errors_stride, tid, part4);
+    }
     const int r0 = by * TS, c0 = bx * TS;
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
@@ -1100,7 +1105,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
     (void)f;
     const size_t padb = align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb);
     return 2 * padb + align_up((size_t)B * N * h * w * eb) +
-           2 * align_up((size_t)(N + 8) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>));
+           2 * align_up((size_t)(N + 8) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>)) +
+           align_up((size_t)B * cdiv(H, 16) * cdiv(W, 16) * sizeof(double));  // per-tile MSE partial sums
 }
 
 // SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
@@ -1126,6 +1132,7 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     const int KP = (N + KS - 1) / KS * KS;
     LTap<T, L> *tyT = ar.take<LTap<T, L>>((size_t)KP * Hp), *txT = ar.take<LTap<T, L>>((size_t)N * Wp);
+    double *epart = ar.take<double>((size_t)B * cdiv(H, 16) * cdiv(W, 16));
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Hp, 64), KP), dim3(64), 0, st, tyT, Hp, H, h, f, bwd, KP, 0);
@@ -1144,13 +1151,13 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
         else
             SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         SRX_LAUNCH(KID_FWD_TILE, k_fwd_tile<T>, fgrid, dim3(256), 0, st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omax_y,
-                   omin_x, omax_x, tl, tl, err, errors ? errors + it : nullptr, n_iter, scale);
-if (sep)
+                   omin_x, omax_x, tl, tl, err, errors ? epart : nullptr, scale);
+        if (sep)
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
-                       (T)N, cur, hr);
+                       (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
         else
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
-                       (T)step, (T)N, cur, hr);
+                       (T)step, (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
     }
     return SRX_OK;
 }

@@ -248,14 +248,6 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-__global__ void __launch_bounds__(256) k_init_errors(double *__restrict__ errors, const double *__restrict__ Vtot, int n_iter,
-                                                     int total, double scale)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < total)
-        errors[i] = Vtot[i / n_iter] * scale;
-}
-
 // ---------------------------------------------------------------------------------------
 // near band (G coordinates p < PBy or q < PBx): LR row/column 0 of a frame is edge-replicated into the 12-px pad, so
 // a pixel there collects several frames and each subtracts its own Y sample.  Built once per call, shared by all
@@ -304,25 +296,31 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ float rcp_count(float c) { return __builtin_amdgcn_rcpf(fmaxf(c, 1.f)); }
 __device__ __forceinline__ double rcp_count(double c) { return 1.0 / fmax(c, 1.0); }
 
+// rows of G per tile: the delta = 0 kernel holds no LDS region, so its tiles can be half as tall -- twice as many blocks,
+// a shorter last round on a single large frame (3185 tiles were 2.07 rounds of 1536 resident blocks: 3 in practice)
+template <typename T, bool ZERO> struct FwdRows {
+    static constexpr int v = (ZERO && TileCfg<T>::T_HR == 64) ? 32 : TileCfg<T>::T_HR;
+};
+
 template <typename T, bool ZERO>
 __global__ void __launch_bounds__(256)
     k_fwd_mosaic(const T *__restrict__ bimg, int Hp, int Wp, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
                  int Wg, MosaicArgs<T> ma, const T *__restrict__ Mu, const int *__restrict__ ncu,
-                 const int *__restrict__ nyx, int NS, int NB, T *__restrict__ G, double *__restrict__ errors,
-                 int errors_stride, double scale, int dbg)
+                 const int *__restrict__ nyx, int NS, int NB, T *__restrict__ G, double *__restrict__ epart, double scale,
+                 int dbg)
 {
-    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
+    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, TSY = FwdRows<T, ZERO>::v, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
     __shared__ T reg[ZERO ? 1 : FR * LD];
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, by, b;
     xcd_block(bx, by, b);
-    const int p0 = by * TS, q0 = bx * TS;
+    const int p0 = by * TSY, q0 = bx * TS;
     const int H = Hp - 2 * SRX_NPAD, W = Wp - 2 * SRX_NPAD;
     const T *src = bimg + (size_t)b * H * W;  // plain blurred plane; its 12-px edge extension is applied on the fly
     // far-field operands of this thread's TS*TS/256 pixels, fetched up front (clamped addresses) so that their
     // latency hides behind the tile's prefilter
-    constexpr int NPX = TS * TS / 256;
+    constexpr int NPX = TSY * TS / 256;
     T Cv[NPX], Mv[NPX];
     const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(Cg, (size_t)Hg * Wg);
     const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(Mg + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
@@ -383,22 +381,30 @@ __global__ void __launch_bounds__(256)
     const bool qok = qg < Wg && qg >= ma.PBx && !(dbg & 8);
     T *Gp = G + (size_t)b * Hg * Wg + qg;
     const bool has_near = p0 < ma.PBy || q0 < ma.PBx;                                      // block-uniform
-    const bool fast = !has_near && p0 + TS <= Hg && q0 + TS <= Wg && !(dbg & 8);  // block-uniform
+    const bool fast = !has_near && p0 + TSY <= Hg && q0 + TS <= Wg && !(dbg & 8);  // block-uniform
     // all of this thread's Y samples first, unconditionally (clamped into the region: values of pixels that are
     // not stored are never used), so that the LDS reads are one batch instead of one round trip per pixel
     T Yv[NPX];
+    if constexpr (ZERO && TS == 64) {  // Y[P, Q] = b[clamp(P - 11), clamp(Q - 11)]: a row per wave, so again buffer loads
+        const __amdgpu_buffer_rsrc_t rsB = fused::plane_rsrc(src, (size_t)H * W);
+        const int vq = min(max(Q + 1 - SRX_NPAD, 0), W - 1) * (int)sizeof(T);
 #pragma unroll
-    for (int j = 0; j < NPX; j++) {
-        const int P = p0 + prow + j * RPJ - ma.Dy;
-        Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
+        for (int j = 0; j < NPX; j++)
+            Yv[j] = fused::buf_load<T>(rsB, vq, min(max(p0 + uwave + 4 * j - ma.Dy + 1 - SRX_NPAD, 0), H - 1) * W * (int)sizeof(T));
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const int P = p0 + prow + j * RPJ - ma.Dy;
+            Yv[j] = ZERO ? Y(P, Q) : reg[max(P - pa, 0) * LD + max(Q - qa, 0)];
+        }
     }
     // ---- near band of this tile, without the replicated rows < RSy / columns < RSx (nobody computes those: the
     // backward kernel reads row RSy / column RSx instead), NEAR_B pixels per thread and trip.  The table loads of a trip are issued together, the first trip's before the far-field pass
     constexpr int NEAR_B = 2;
-    // top part: rows [rt0, rt0 + ntop) x columns [ct0, q0 + TS); left part: rows [rl0, p0 + TS) x columns [ct0, ct0 + ncl)
-    const int rt0 = max(p0, ma.RSy), ntop = max(min(ma.PBy, p0 + TS) - rt0, 0), ct0 = max(q0, ma.RSx), nct = q0 + TS - ct0;
+    // top part: rows [rt0, rt0 + ntop) x columns [ct0, q0 + TS); left part: rows [rl0, p0 + TSY) x columns [ct0, ct0 + ncl)
+    const int rt0 = max(p0, ma.RSy), ntop = max(min(ma.PBy, p0 + TSY) - rt0, 0), ct0 = max(q0, ma.RSx), nct = q0 + TS - ct0;
     const int rl0 = max(p0, ma.PBy), ncl = max(min(ma.PBx, q0 + TS) - ct0, 0), ncl1 = max(ncl, 1);
-    const int ntopc = ntop * nct, nn = (dbg & 8) ? 0 : ntopc + (p0 + TS - rl0) * ncl;  // 0 unless has_near
+    const int ntopc = ntop * nct, nn = (dbg & 8) ? 0 : ntopc + max(p0 + TSY - rl0, 0) * ncl;  // 0 unless has_near
     const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
     T *Gb = G + (size_t)b * Hg * Wg;
     const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
@@ -498,11 +504,8 @@ __global__ void __launch_bounds__(256)
     if (lane == 0)
         part[wave] = sq;
     __syncthreads();
-    if (tid == 0 && errors) {
-        const double s = part[0] + part[1] + part[2] + part[3];
-        if (s != 0.0)
-            atomicAdd(&errors[(size_t)b * errors_stride], s * scale);
-    }
+    if (tid == 0 && epart)  // this tile's share of the MSE trace; summed by k_bwd_mosaic (err_trace_reduce)
+        epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = (part[0] + part[1] + part[2] + part[3]) * scale;
     SRX_STAMP(0, 5);
 }
 
@@ -513,7 +516,8 @@ __global__ void __launch_bounds__(256)
 template <typename T, bool ZERO, bool SEP>
 __global__ void __launch_bounds__(256)
     k_bwd_mosaic(const T *__restrict__ G, int Hg, int Wg, MosaicArgs<T> ma, int H, int W, Kernel7<T> kt, T step, T n,
-                 const T *__restrict__ hr_in, T *__restrict__ hr_out, int dbg)
+                 const T *__restrict__ hr_in, T *__restrict__ hr_out, const double *__restrict__ epart, int nblk,
+                 const double *__restrict__ Vtot, double scale, double *__restrict__ errors, int errors_stride, int dbg)
 {
     constexpr int R = ZERO ? 0 : TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R, LD = BR + 3;  // odd
     __shared__ T reg[(BR + 3) * LD];
@@ -523,6 +527,10 @@ __global__ void __launch_bounds__(256)
     xcd_block(bx, by, b);
     const int r0 = by * TS, c0 = bx * TS;
     const T *src = G + (size_t)b * Hg * Wg;
+    if (errors && bx == 0 && by == 0) {  // MSE trace of this iteration: the forward kernel's per-tile sums + the constant part
+        __shared__ double part4[4];
+        err_trace_reduce(epart, nblk, b, Vtot[b] * scale, errors + (size_t)b * errors_stride, wave * 64 + lane, part4);
+    }
     // padded rows of c' the 7x7 window of this tile reads: [r0+9, r0+TS+15); R more on each side for the recursion
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
@@ -802,7 +810,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
     const size_t NS = (N + 3) & ~3;
     return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
            align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
-           align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int));
+           align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int)) +
+           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
 
 template <typename T>
@@ -823,6 +832,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = ar.take<double>(B);
     int *ncu = ar.take<int>(NB), *nyx = ar.take<int>((size_t)NB * NS);
+    double *epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
@@ -870,31 +880,27 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
-    if (errors) {
-        const int total = B * n_iter;
-        hipLaunchKernelGGL(k_init_errors, dim3(cdiv(total, 256)), dim3(256), 0, st, errors, Vtot, n_iter, total, scale);
-        SRX_CHECK_LAUNCH();
-    }
     constexpr int TS = TileCfg<T>::T_HR;
     const int dbg = getenv("SRX_DBG") ? atoi(getenv("SRX_DBG")) : 0;  // timing ablations only (results are wrong)
     const size_t dbg_lds = getenv("SRX_DBG_LDS") ? (size_t)atoi(getenv("SRX_DBG_LDS")) : 0;  // extra LDS: caps blocks per CU
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
-    const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
+    const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, zero ? FwdRows<T, true>::v : TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
-        double *eo = errors ? errors + it : nullptr;
+        double *eo = errors ? errors + it : nullptr, *ep = errors ? epart : nullptr;
         if (sep)
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         if (zero)
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Mu, ncu,
-                       nyx, NS, NB, G, eo, n_iter, scale, dbg);
+                       nyx, NS, NB, G, ep, scale, dbg);
         else
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, false>), fgrid, dim3(256), dbg_lds, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma,
-                       Mu, ncu, nyx, NS, NB, G, eo, n_iter, scale, dbg);
+                       Mu, ncu, nyx, NS, NB, G, ep, scale, dbg);
 #define SRX_BWDM(Z_, S_)                                                                                             \
-    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, dbg)
+    SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, \
+               epart, (int)(fgrid.x * fgrid.y), Vtot, scale, eo, n_iter, dbg)
         if (zero) {
             if (sep)
                 SRX_BWDM(true, true);
