@@ -154,8 +154,8 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
     bz = (int)(id / (gx * gy));
 }
 
-// MSE trace without atomics.  Every block of a forward kernel stores its partial sum at epart[item * nblk + tile] (tile =
-// by * gridDim.x + bx of the remapped block); the block (0, 0) of that item in the following backward kernel adds them up
+// MSE trace without atomics.  Every wave of a forward kernel stores its partial sum at epart[item * nblk + 4 tile + wave]
+// (tile = by * gridDim.x + bx of the remapped block, nblk = 4 tiles per item); the block (0, 0) of that item in the following backward kernel adds them up
 // in a fixed order: deterministic, and nothing serialises when ONE large frame has thousands of tiles (3185 double
 // atomics into one address cost 35 us of a 51 us kernel).  `part4`: 4 doubles of LDS.  Block-uniform call; has a barrier.
 __device__ __forceinline__ void err_trace_reduce(const double *__restrict__ epart, int nblk, int item, double base,
