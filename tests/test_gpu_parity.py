@@ -384,3 +384,29 @@ def test_full_size_linearity():
         lhs = fn(0.25 * x + 0.5 * y)
         rhs = 0.25 * fn(x) + 0.5 * fn(y)
         assert float((lhs - rhs).abs().max()) < 2e-3
+
+
+def test_full_frame_paths_agree_and_trace_is_deterministic():
+    """The reference's own full-frame shapes, noisy frames, one item.  mono_cal_target (N = 5 nominal, f = 2, 3072x4096:
+    the delta = 0 mosaic kernels, 6370 forward tiles) against the per-frame fused path; rgb_cal_target (N = 4 measured
+    shifts, 1536x2048: per-frame fused) against the composed path.  The MSE trace is a fixed-order sum of per-wave partial
+    sums (no atomics): two runs are bit-identical."""
+    S.set_precision("f32")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    for f, shifts, psf, tile, reps, want, other in (
+            (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "mosaic", S.FLAG_PER_FRAME),
+            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "fused", S.FLAG_COMPOSED)):
+        big = torch.from_numpy(synth.truth_image(*tile, seed=6)).cuda().float().repeat(*reps)[None].contiguous()
+        lr = torch.stack([S.forward_model_batched(big, psf, s, f) for s in shifts], dim=1)
+        lr = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255).contiguous()
+        saa = S.shift_and_add_batched(lr, shifts, f)
+        hr_a, e_a = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5)
+        assert S.last_path() == want
+        hr_b, e_b = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5)
+        assert torch.equal(hr_a, hr_b) and torch.equal(e_a, e_b)
+        hr_o, e_o = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5, flags=other)
+        assert S.last_path() != want
+        assert float((hr_a - hr_o).abs().max()) < 5e-3
+        np.testing.assert_allclose(e_a.cpu().numpy(), e_o.cpu().numpy(), rtol=2e-5)
+        assert float(e_a[0, -1]) < float(e_a[0, 0])
