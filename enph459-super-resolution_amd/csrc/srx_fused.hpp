@@ -534,7 +534,8 @@ __global__ void __launch_bounds__(256) k_crop_div(const T *__restrict__ vpad, in
 // The recursive prefilter has a global dependence along each line, but its impulse response
 // decays as |z|^n, z = sqrt(3)-2: a tile that starts the recursion R samples outside the region
 // it needs (from the steady state of a constant signal) reproduces the full-line result to |z|^R times the
-// signal's local deviation.  R = 32 for double (5e-19).  R = 11 for float: |z|^11 = 5e-7, and with it the forward
+// signal's local deviation.  R = 23 for double (|z|^23 = 7e-14: ~3e-11 DN at worst, max |gpu - oracle| stays 2.8e-13 on C2;
+// the 81^2 tile is 52.5 KB, three blocks per CU, 1.8x the speed of R = 32).  R = 11 for float: |z|^11 = 5e-7, and with it the forward
 // tile (64 + 3 + 2 R = 89 wide) is 31.7 KB of LDS, five blocks per CU instead of four (-10 % on k_fwd_mosaic);
 // against R = 12 the C2 result does not move in any printed digit (tools/accuracy.py: max |gpu - oracle| 1.856e-4 DN,
 // PSNR(gpu, oracle) 136.78 dB either way -- float rounding of the 80 iterations dominates).  Where the region
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(256) k_crop_div(const T *__restrict__ vpad, in
 // =========================================================================================
 template <typename T> struct TileCfg;
 template <> struct TileCfg<float> { static constexpr int R = 11, T_HR = 64; };
-template <> struct TileCfg<double> { static constexpr int R = 32, T_HR = 32; };
+template <> struct TileCfg<double> { static constexpr int R = 23, T_HR = 32; };
 
 // One line of the recursive cubic-spline prefilter on LDS, optionally fused with the 4-tap spline FIR:
 //   MODE 0: line <- P(line)                                      (n = n_in outputs)
