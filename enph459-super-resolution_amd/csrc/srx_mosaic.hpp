@@ -32,7 +32,7 @@ namespace mosaic {
 // Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
 // buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
 #ifdef SRX_STAMPS
-__device__ unsigned long long srx_dbg_stamps[2][8][40000];  // [kernel][phase][block]
+__device__ unsigned long long srx_dbg_stamps[3][8][40000];  // [kernel][phase][block]
 #define SRX_STAMP(K, PH)                                                                                       \
     do {                                                                                                        \
         if (threadIdx.x == 0 && threadIdx.y == 0) {                                                             \
@@ -730,10 +730,12 @@ __global__ void __launch_bounds__(256)
                 patch[py * PD + px] = pre[i];
         }
     };
+    SRX_STAMP(2, 0);
     geometry(0);
     fetch(0);
     stash();
     __syncthreads();
+    SRX_STAMP(2, 1);
     for (int k = 0; k < N; k++) {
         tY = tYn;
         // row pass: rows[py][cc] = sum_j zx[x(cc)].w[j] * patch[py][idx[j]]
@@ -759,6 +761,8 @@ __global__ void __launch_bounds__(256)
         }
         const int cjy0 = jy0;
         __syncthreads();
+        if (k == 0)
+            SRX_STAMP(2, 2);
         if (k + 1 < N) {  // next frame's patch and taps: in flight during the column pass
             geometry(k + 1);
             fetch(k + 1);
@@ -777,10 +781,15 @@ __global__ void __launch_bounds__(256)
                                  "+v"(acc[t - 2]), "+v"(acc[t - 1]), "+v"(acc[t])::"memory");
             }
         }
+        if (k == 0)
+            SRX_STAMP(2, 3);
         if (k + 1 < N)
             stash();  // the row pass of this frame is done with the patch
         __syncthreads();
+        if (k == 0)
+            SRX_STAMP(2, 4);
     }
+    SRX_STAMP(2, 5);
 #pragma unroll
     for (int t = 0; t < NT; t++)
         if (rrok && cb + t < ncw)
@@ -789,11 +798,13 @@ __global__ void __launch_bounds__(256)
     const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
     fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid, r_lo);
     fused::walk_pass_2seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid, c0 + SRX_NPAD - qa);
+    SRX_STAMP(2, 6);
     for (int idx = tid; idx < TS * TS; idx += 256) {
         const int r = r0 + idx / TS, c = c0 + idx % TS;
         if (r < H && c < W)
             out[((size_t)b * H + r) * W + c] = reg[(r + SRX_NPAD - pa) * LD + (c + SRX_NPAD - qa)] / inv_n_div;
     }
+    SRX_STAMP(2, 7);
 }
 
 // ---------------------------------------------------------------------------------------

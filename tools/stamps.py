@@ -18,19 +18,21 @@ f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), 1024
 lr = torch.rand((B, 16, 64, 64), device="cuda") * 255
 saa = S.shift_and_add_batched(lr, shifts, f)
 S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
-buf = np.zeros((2, 8, 40000), dtype=np.uint64)
+buf = np.zeros((3, 8, 40000), dtype=np.uint64)
 lib = _lib.load()
 lib.srx_debug_stamps.argtypes = [ctypes.c_void_p]
 assert lib.srx_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 names = {0: ("k_fwd_mosaic", ["prefetch M,C", "load region + store", "column pass", "row pass", "pixel phase", "reduce+atomic"]),
-         1: ("k_bwd_mosaic", ["prefetch hr", "load region + store", "column pass", "row pass", "zero border", "blur+update"])}
+         1: ("k_bwd_mosaic", ["prefetch hr", "load region + store", "column pass", "row pass", "zero border", "blur+update"]),
+         2: ("k_saa_tile", ["start", "frame 0 fetch+stash", "frame 0 row pass", "frame 0 column pass", "frame 0 stash next", "frames 1..N-1", "region + walks", "output"])}
 for k, (kn, ph) in names.items():
     t = buf[k].astype(np.int64)
     nb = 25600 if k == 0 else 16384
-    ok = (t[0, :nb] > 0) & (t[5, :nb] > t[0, :nb])
-    tot = (t[5, :nb] - t[0, :nb])[ok]
+    last = len(ph) - 1
+    ok = (t[0, :nb] > 0) & (t[last, :nb] > t[0, :nb])
+    tot = (t[last, :nb] - t[0, :nb])[ok]
     print(f"{kn}: blocks {ok.sum()}, median cycles/block {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f})")
-    for i in range(5):
+    for i in range(last):
         d = (t[i + 1, :nb] - t[i, :nb])[ok]
         print(f"    {ph[i + 1]:22s} median {np.median(d):8.0f}  mean {d.mean():8.0f}  share of mean {100 * d.mean() / tot.mean():5.1f} %")
     if k == 0:  # fwd: 5 x 5 tiles per item, x fastest -- edge classes (assumes the C2 shape and no XCD remap effect on class sizes)
