@@ -544,37 +544,118 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int o = 0; o < 8; o++)
             hv[half][o] = fused::buf_load<T>(rs_in, hcol, min(r0 + half * 32 + uw * 8 + o, H - 1) * W * (int)sizeof(T));
-    if (ZERO) {
-        // c'[p, q] = G[p+1, q+1]
-        fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
-        __syncthreads();
-    } else {
+    const T sn = step / n;  // hr + step * corr / N evaluated as hr + corr * (step / N): one rounding of the factor (<= 1 ulp)
+    const int c = c0 + lane;
+    if constexpr (SEP && !ZERO) {
+        // Separable PSF: B' = (7 taps down) x (7 taps across), and the taps down commute with everything that acts along
+        // x.  Column walk -> zero the rows outside the image -> blur DOWN (TS+6 rows -> TS rows, all region columns) -> row
+        // walk over TS lines -> zero the columns outside -> blur ACROSS + update.  With TS+6 lines the row walk kept two
+        // of the four waves busy for 6 lines each (a full instruction stream: 16 % of this kernel's VALU work).
+        constexpr int RW = TileCfg<T>::R, RH = TS / 2, WN = TS + 6;
         fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa, qa, ma.RSy, ma.RSx, nr + 3, nc + 3, wave, lane);
         __syncthreads();
         SRX_STAMP(1, 1);
-        constexpr int RW = TileCfg<T>::R;
-        const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
-        fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid, r_lo);
+        const int r_lo = r0 + 9 - pa, ncw = nc + 3;
+        fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, ncw, nr + 3, pa == 0, ma.wby, tid, r_lo);
         SRX_STAMP(1, 2);
-        fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid, c0 + 9 - qa);
+        T *wrow = reg + r_lo * LD;  // window row 0 = image row r0 - 3
+        // B' sees zeros outside the image: of the window rows only the three just above row 0 / below row H-1 are read
+        if (r0 == 0 || r0 + TS + 3 > H) {
+            const int wrb = H - r0 + 3;  // window row of image row H
+            for (int idx = tid; idx < 6 * ncw; idx += 256) {
+                const int s6 = idx / ncw, cc = idx - s6 * ncw, o = s6 % 3;
+                const int wr = s6 < 3 ? o : wrb + o;
+                if (s6 < 3 ? r0 == 0 : wr < WN)
+                    wrow[wr * LD + cc] = 0;
+            }
+            __syncthreads();
+        }
+        {  // blur down: wave (chunk, half) owns columns 64 chunk + lane, output rows [RH half, RH half + RH)
+            const int chunk = uw & 1, half = uw >> 1, cc = min(lane + 64 * chunk, ncw - 1);
+            const T *colp = wrow + half * RH * LD + cc;
+            T in[RH + 6], out[RH];
+#pragma unroll
+            for (int u = 0; u < RH + 6; u++)
+                in[u] = colp[u * LD];
+#pragma unroll
+            for (int o = 0; o < RH; o++) {
+                T a = 0;
+#pragma unroll
+                for (int u = 0; u < 7; u++)
+                    a += kt.cy[u] * in[o + u];
+                out[o] = a;
+            }
+            __syncthreads();  // every wave has read its RH + 6 rows
+            if (lane + 64 * chunk < ncw) {
+#pragma unroll
+                for (int o = 0; o < RH; o++)
+                    wrow[(half * RH + o) * LD + cc] = out[o];  // window row o now holds image row r0 + o
+            }
+            __syncthreads();
+        }
+        fused::walk_pass_2seg<T, 1, 1, RW>(wrow, LD, TS, ncw, qa == 0, ma.wbx, tid, c0 + 9 - qa);
         SRX_STAMP(1, 3);
-    }
-    fused::zero_outside_image<T, TS, LD>(reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa), r0, c0, H, W, tid);
-    SRX_STAMP(1, 4);
-    const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
-    const int c = c0 + lane;
-    const T sn = step / n;  // hr + step * corr / N evaluated as hr + corr * (step / N): one rounding of the factor (<= 1 ulp)
+        T *win = wrow + (c0 + 9 - qa);  // window column 0 = image column c0 - 3
+        if (c0 == 0 || c0 + TS + 3 > W) {
+            const int wcb = W - c0 + 3;
+            for (int idx = tid; idx < 6 * TS; idx += 256) {
+                const int s6 = idx / TS, rr = idx - s6 * TS, o = s6 % 3;
+                const int wc = s6 < 3 ? o : wcb + o;
+                if (s6 < 3 ? c0 == 0 : wc < WN)
+                    win[rr * LD + wc] = 0;
+            }
+            __syncthreads();
+        }
+        SRX_STAMP(1, 4);
 #pragma unroll
-    for (int half = 0; half < TS / 32; half++) {
-        if (lane < TS && !(dbg & 64)) {
-            T a8[8];
-            corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
+        for (int half = 0; half < TS / 32; half++) {
+            if (lane < TS && !(dbg & 64)) {
 #pragma unroll
-            for (int o = 0; o < 8; o++) {
-                const int r = r0 + half * 32 + uw * 8 + o;
-                if (r < H && c < W) {
-                    const T v = hv[half][o] + a8[o] * sn;
-                    fused::buf_store<T>(v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v), rs_out, hcol, r * W * (int)sizeof(T));
+                for (int o = 0; o < 8; o++) {
+                    const int rr = half * 32 + uw * 8 + o, r = r0 + rr;
+                    const T *row = win + rr * LD + lane;
+                    T a = 0;
+#pragma unroll
+                    for (int u = 0; u < 7; u++)
+                        a += kt.cx[u] * row[u];
+                    if (r < H && c < W) {
+                        const T v = hv[half][o] + a * sn;
+                        fused::buf_store<T>(v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v), rs_out, hcol, r * W * (int)sizeof(T));
+                    }
+                }
+            }
+        }
+    } else {
+        if (ZERO) {
+            // c'[p, q] = G[p+1, q+1]
+            fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa + 1, qa + 1, ma.RSy, ma.RSx, nr, nc, wave, lane);
+            __syncthreads();
+        } else {
+            fused::load_region_lo<T, BR + 3, BR + 3, sizeof(T) == 4 ? 26 : 8>(reg, LD, src, Hg, Wg, pa, qa, ma.RSy, ma.RSx, nr + 3, nc + 3, wave, lane);
+            __syncthreads();
+            SRX_STAMP(1, 1);
+            constexpr int RW = TileCfg<T>::R;
+            const int r_lo = r0 + 9 - pa, r_hi = min(r0 + TS + 15, Hp) - pa;
+            fused::walk_pass_2seg<T, LD, 1, RW>(reg, 1, nc + 3, nr + 3, pa == 0, ma.wby, tid, r_lo);
+            SRX_STAMP(1, 2);
+            fused::walk_pass_2seg<T, 1, 1, RW>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), nc + 3, qa == 0, ma.wbx, tid, c0 + 9 - qa);
+            SRX_STAMP(1, 3);
+        }
+        fused::zero_outside_image<T, TS, LD>(reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa), r0, c0, H, W, tid);
+        SRX_STAMP(1, 4);
+        const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
+#pragma unroll
+        for (int half = 0; half < TS / 32; half++) {
+            if (lane < TS && !(dbg & 64)) {
+                T a8[8];
+                corr7_strip8<T, LD, SEP>(win + half * 32 * LD, lane, wave, kt, a8);
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int r = r0 + half * 32 + uw * 8 + o;
+                    if (r < H && c < W) {
+                        const T v = hv[half][o] + a8[o] * sn;
+                        fused::buf_store<T>(v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v), rs_out, hcol, r * W * (int)sizeof(T));
+                    }
                 }
             }
         }
