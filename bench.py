@@ -115,9 +115,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
     ap.add_argument("--iters", type=int, default=80, help="IBP iterations (reference default 80)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_rgb"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_rgb", "c3_f4"],
                     help="c2 (default, the headline): 1024 x4 patches, N=16 phases; c3_mono / c3_rgb: the reference's own "
-                         "full-frame shapes (mono_cal_target N=5 nominal f=2 3072x4096; rgb_cal_target N=4 measured f=2 1536x2048)")
+                         "full-frame shapes (mono_cal_target N=5 nominal f=2 3072x4096; rgb_cal_target N=4 measured f=2 1536x2048); "
+                         "c3_f4: the x4 variant of SURVEY 8d, 768x1024 -> 3072x4096, all 16 phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -155,6 +156,9 @@ def main():
         psf = synth.asymmetric_psf()
         n_iter = args.iters if args.iters != 80 else 50
         wl_name = "C3-rgb: the reference's rgb_cal_target shape, 768x1024 LR -> 1536x2048, N=4 measured shifts, asymmetric PSF"
+    elif args.workload == "c3_f4":   # "plus f=4 variant 768x1024 -> 3072x4096"
+        f, lr_hw, shifts, B = 4, (768, 1024), synth.phase_shifts(4), (args.batch if args.batch != 1024 else 1)
+        wl_name = "C3-f4: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all 4x4 sub-pixel phases), Gaussian PSF"
     N = len(shifts)
     h, w = lr_hw
     H, W = h * f, w * f
