@@ -154,16 +154,28 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
     bz = (int)(id / (gx * gy));
 }
 
-// MSE trace without atomics.  Every wave of a forward kernel stores its partial sum at epart[item * nblk + 4 tile + wave]
-// (tile = by * gridDim.x + bx of the remapped block, nblk = 4 tiles per item); the block (0, 0) of that item in the following backward kernel adds them up
+// MSE trace without atomics.  Every block of a forward kernel stores its partial sum at epart[item * nblk + tile] (tile =
+// by * gridDim.x + bx of the remapped block); the block (0, 0) of that item in the following backward kernel adds them up
 // in a fixed order: deterministic, and nothing serialises when ONE large frame has thousands of tiles (3185 double
-// atomics into one address cost 35 us of a 51 us kernel).  `part4`: 4 doubles of LDS.  Block-uniform call; has a barrier.
+// atomics into one address cost 35 us of a 51 us kernel).  Eight independent loads per thread and trip: that one block is
+// a serial tail of its kernel (with per-wave instead of per-tile partials, 25 480 values, it was 14 us of 47).
+// `part4`: 4 doubles of LDS.  Block-uniform call; has barriers.
 __device__ __forceinline__ void err_trace_reduce(const double *__restrict__ epart, int nblk, int item, double base,
                                                  double *__restrict__ out, int tid, double *part4)
 {
-    double s = 0.0;
-    for (int i = tid; i < nblk; i += 256)
-        s += epart[(size_t)item * nblk + i];
+    const double *p = epart + (size_t)item * nblk;
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        acc[u] = 0.0;
+    for (int i = tid; i < nblk; i += 256 * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = i + 256 * u;
+            acc[u] += k < nblk ? p[k] : 0.0;
+        }
+    }
+    double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     s = wave_sum(s);
     if ((tid & 63) == 0)
         part4[tid >> 6] = s;

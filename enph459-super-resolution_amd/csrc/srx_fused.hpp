@@ -828,6 +828,7 @@ __global__ void __launch_bounds__(256)
 {
     constexpr int R = TileCfg<T>::R, FR = TileCfg<T>::T_HR + 12 + 2 * R, LD = FR + 1;
     __shared__ T reg[FR * LD];
+    __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, by, b;
     xcd_block(bx, by, b);
@@ -867,8 +868,11 @@ __global__ void __launch_bounds__(256)
         }
     }
     sq = wave_sum(sq);
-    if (lane == 0 && epart)  // this wave's share of the MSE trace; summed by k_bwd_tile (err_trace_reduce)
-        epart[(((size_t)b * gridDim.y + by) * gridDim.x + bx) * 4 + wave] = sq * scale;
+    if (lane == 0)
+        part[wave] = sq;
+    __syncthreads();
+    if (tid == 0 && epart)  // this tile's share of the MSE trace; summed by k_bwd_tile (err_trace_reduce)
+        epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
 }
 
 // Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= L LR samples
@@ -1103,7 +1107,7 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
     const size_t padb = align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb);
     return 2 * padb + align_up((size_t)B * N * h * w * eb) +
            2 * align_up((size_t)(N + 8) * (H + W + 4 * SRX_NPAD) * sizeof(LTap<double, 2>)) +
-           align_up((size_t)B * cdiv(H, 16) * cdiv(W, 16) * 4 * sizeof(double));  // per-wave MSE partial sums
+           align_up((size_t)B * cdiv(H, 16) * cdiv(W, 16) * sizeof(double));  // per-tile MSE partial sums
 }
 
 // SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
@@ -1129,7 +1133,7 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     const int KP = (N + KS - 1) / KS * KS;
     LTap<T, L> *tyT = ar.take<LTap<T, L>>((size_t)KP * Hp), *txT = ar.take<LTap<T, L>>((size_t)N * Wp);
-    double *epart = ar.take<double>((size_t)B * cdiv(H, 16) * cdiv(W, 16) * 4);
+    double *epart = ar.take<double>((size_t)B * cdiv(H, 16) * cdiv(W, 16));
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Hp, 64), KP), dim3(64), 0, st, tyT, Hp, H, h, f, bwd, KP, 0);
@@ -1151,10 +1155,10 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
                    omin_x, omax_x, tl, tl, err, errors ? epart : nullptr, scale);
         if (sep)
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
-                       (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y * 4), errors ? errors + it : nullptr, n_iter);
+                       (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
         else
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
-                       (T)step, (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y * 4), errors ? errors + it : nullptr, n_iter);
+                       (T)step, (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
     }
     return SRX_OK;
 }

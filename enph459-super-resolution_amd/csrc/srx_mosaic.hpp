@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(256)
 {
     constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, TSY = FwdRows<T, ZERO>::v, FR = TS + 3 + 2 * R, LD = FR;  // FR is odd
     __shared__ T reg[ZERO ? 1 : FR * LD];
+    __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, by, b;
     xcd_block(bx, by, b);
@@ -500,8 +501,11 @@ __global__ void __launch_bounds__(256)
     }
     SRX_STAMP(0, 4);
     sq = wave_sum(sq + (double)sqt);
-    if (lane == 0 && epart)  // this wave's share of the MSE trace; summed by k_bwd_mosaic (err_trace_reduce): no barrier here
-        epart[(((size_t)b * gridDim.y + by) * gridDim.x + bx) * 4 + wave] = sq * scale;
+    if (lane == 0)
+        part[wave] = sq;
+    __syncthreads();
+    if (tid == 0 && epart)  // this tile's share of the MSE trace; summed by k_bwd_mosaic (err_trace_reduce)
+        epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
     SRX_STAMP(0, 5);
 }
 
@@ -899,7 +903,7 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
     return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
            align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
            align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int)) +
-           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * 4 * sizeof(double));
+           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
 
 template <typename T>
@@ -920,7 +924,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = ar.take<double>(B);
     int *ncu = ar.take<int>(NB), *nyx = ar.take<int>((size_t)NB * NS);
-    double *epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32) * 4);  // per-wave MSE partial sums of one iteration
+    double *epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
@@ -988,7 +992,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        Mu, ncu, nyx, NS, NB, G, ep, scale, dbg);
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, \
-               epart, (int)(fgrid.x * fgrid.y * 4), Vtot, scale, eo, n_iter, dbg)
+               epart, (int)(fgrid.x * fgrid.y), Vtot, scale, eo, n_iter, dbg)
         if (zero) {
             if (sep)
                 SRX_BWDM(true, true);
