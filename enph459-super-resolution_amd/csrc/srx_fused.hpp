@@ -807,6 +807,115 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     __syncthreads();
 }
 
+// The same pass when there are at most 64 lines: FOUR threads per line, one WAVE per quarter (lane = line), so all four
+// waves of the block walk instead of two and the serial chain is n/4 + R steps instead of n/2 + R.  Quarter s owns outputs
+// [lo_s, hi_s); it starts its causal recursion R samples early and its anticausal recursion R samples late from values
+// pre-loaded into registers before a neighbour may overwrite them, as in walk_pass_2seg.  Falls back to walk_pass_2seg
+// for more lines or short lines (block-uniform).
+template <typename T, int S, int MODE, int R>
+__device__ __forceinline__ void walk_pass_4seg(T *__restrict__ base, int line_pitch, int nlines, int n_in, bool edge,
+                                               const T *__restrict__ w, int tid, int need_lo = 0)
+{
+    constexpr int O = MODE == 1 ? 3 : 0;
+    const int n = MODE == 1 ? n_in - 3 : n_in;
+    // the cuts need lo_1 >= R, hi_2 + R <= n and quarters of at least 8 outputs: all hold for n - need_lo >= 4 (R + 8)
+    if (nlines > 64 || n - need_lo < 4 * (R + 8)) {
+        walk_pass_2seg<T, S, MODE, R>(base, line_pitch, nlines, n_in, edge, w, tid, need_lo);
+        return;
+    }
+    const T z = pole<T>(), zfin = z / (z - (T)1), kq = (T)-6 * z;
+    const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
+    const int seg = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool active = lane < nlines, first = seg == 0, last = seg == 3;
+    T *line = base + (active ? lane : 0) * line_pitch;
+    // quarters of the part somebody reads, [need_lo, n), cut at multiples of 8; the first one also carries [0, need_lo)
+    const int span = n - need_lo;
+    const int lo = first ? 0 : (need_lo + span * seg / 4) & ~7;
+    const int hi = last ? n : (need_lo + span * (seg + 1) / 4) & ~7;
+    WalkState<T> st;
+    st.g0 = st.g1 = st.g2 = 0;
+    T pre[R + 3], post[3];
+    // ---- A: inputs a neighbouring quarter is about to overwrite ----
+    if (active && !first) {
+#pragma unroll
+        for (int j = 0; j < R + O; j++)
+            pre[j] = line[(lo - R + j) * S];
+    }
+    if (MODE == 1 && active && !last) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            post[j] = line[(hi + j) * S];
+    }
+    __syncthreads();
+    // ---- B: causal ----
+    if (active) {
+        if (first) {
+            causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
+        } else if (MODE == 1) {  // warm-up over the R pre-loaded samples [lo-R, lo), steady-state start
+            st.g0 = pre[0], st.g1 = pre[1], st.g2 = pre[2];
+            st.prev = (w0 * pre[0] + w1 * pre[1] + w2 * pre[2] + w3 * pre[3]) / ((T)1 - z);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const T v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * pre[j + 3];
+                st.g0 = st.g1, st.g1 = st.g2, st.g2 = pre[j + 3];
+                st.prev = v + z * st.prev;
+            }
+        } else {
+            st.prev = pre[0] / ((T)1 - z);
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                st.prev = pre[j] + z * st.prev;
+        }
+        if (MODE == 1 && !last) {
+            causal_run<T, S, MODE>(line, lo, hi - 8, st, w0, w1, w2, w3);
+            T x[8];  // last 8 outputs: the three newest FIR inputs come from registers
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                x[u] = u >= 5 ? post[u - 5] : line[(hi - 8 + u + O) * S];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const T v = w0 * st.g0 + w1 * st.g1 + w2 * st.g2 + w3 * x[u];
+                st.g0 = st.g1, st.g1 = st.g2, st.g2 = x[u];
+                st.prev = v + z * st.prev;
+                x[u] = kq * st.prev;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                line[(hi - 8 + u) * S] = x[u];
+        } else {
+            causal_run<T, S, MODE>(line, lo, hi, st, w0, w1, w2, w3);
+        }
+    }
+    __syncthreads();
+    // ---- C: q[hi, hi+R) (= -z c+) before the next quarter's anticausal pass overwrites it ----
+    if (active && !last) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            pre[j] = line[(hi + j) * S];
+    }
+    __syncthreads();
+    // ---- D: anticausal ----
+    if (active) {
+        if (last) {
+            st.next = st.prev * ((T)6 * zfin);
+            st.a1 = st.next, st.a2 = 0, st.a3 = 0;
+            if (MODE != 2)
+                line[(n - 1) * S] = st.next;
+            anticausal_run<T, S, MODE>(line, n - 2, lo, st, w0, w1, w2, w3);
+        } else {
+            st.next = pre[R - 1] / ((T)1 - z);
+            st.a1 = st.next, st.a2 = 0, st.a3 = 0;
+#pragma unroll
+            for (int j = R - 2; j >= 0; j--) {
+                st.next = z * st.next + pre[j];
+                st.a3 = st.a2, st.a2 = st.a1, st.a1 = st.next;
+            }
+            anticausal_run<T, S, MODE>(line, hi - 1, first ? need_lo : lo, st, w0, w1, w2, w3);
+        }
+    }
+    __syncthreads();
+}
+
 // in-place 2-D prefilter of an LDS region [nr x nc], row stride LD (odd: conflict-free row walks).
 // Axis 0 runs over all nc columns; axis 1 only over rows [r_lo, r_hi) (the rows a consumer reads).
 template <typename T, int NT, int LD>

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256)
             const int r_lo_w = p0 < ma.PBy ? 0 : r_lo, c_lo_w = q0 < ma.PBx ? 0 : max(0, q0 - ma.Dx - qa);
             fused::walk_pass_2seg<T, LD, 2, R>(reg, 1, nc, nr, pa == 0, ma.wfy, tid, r_lo_w);
             SRX_STAMP(0, 2);
-            fused::walk_pass_2seg<T, 1, 2, R>(reg + r_lo_w * LD, LD, max(r_hi - r_lo_w, 0), nc, qa == 0, ma.wfx, tid, c_lo_w);
+            fused::walk_pass_4seg<T, 1, 2, R>(reg + r_lo_w * LD, LD, max(r_hi - r_lo_w, 0), nc, qa == 0, ma.wfx, tid, c_lo_w);
         }
         __syncthreads();
         SRX_STAMP(0, 3);
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256)
             }
             __syncthreads();
         }
-        fused::walk_pass_2seg<T, 1, 1, RW>(wrow, LD, TS, ncw, qa == 0, ma.wbx, tid, c0 + 9 - qa);
+        fused::walk_pass_4seg<T, 1, 1, RW>(wrow, LD, TS, ncw, qa == 0, ma.wbx, tid, c0 + 9 - qa);
         SRX_STAMP(1, 3);
         T *win = wrow + (c0 + 9 - qa);  // window column 0 = image column c0 - 3
         if (c0 == 0 || c0 + TS + 3 > W) {
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
     fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid, r_lo);
-    fused::walk_pass_2seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid, c0 + SRX_NPAD - qa);
+    fused::walk_pass_4seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid, c0 + SRX_NPAD - qa);
     SRX_STAMP(2, 6);
     for (int idx = tid; idx < TS * TS; idx += 256) {
         const int r = r0 + idx / TS, c = c0 + idx % TS;
