@@ -154,6 +154,24 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
     bz = (int)(id / (gx * gy));
 }
 
+// Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
+// buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
+#ifdef SRX_STAMPS
+__device__ unsigned long long srx_dbg_stamps[4][8][40000];  // [kernel][phase][block]
+#define SRX_STAMP(K, PH)                                                                                       \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && threadIdx.y == 0) {                                                             \
+            unsigned long long _t;                                                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
+            const unsigned _blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+            if (_blk < 40000)                                                                                    \
+                srx_dbg_stamps[K][PH][_blk] = _t;                                                                \
+        }                                                                                                       \
+    } while (0)
+#else
+#define SRX_STAMP(K, PH) do { } while (0)
+#endif
+
 // MSE trace without atomics.  Every block of a forward kernel stores its partial sum at epart[item * nblk + tile] (tile =
 // by * gridDim.x + bx of the remapped block); the block (0, 0) of that item in the following backward kernel adds them up
 // in a fixed order: deterministic, and nothing serialises when ONE large frame has thousands of tiles (3185 double

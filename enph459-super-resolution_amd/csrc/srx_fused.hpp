@@ -1075,22 +1075,31 @@ __device__ __forceinline__ void zero_outside_image(T *__restrict__ win0, int r0,
 // descriptor: address = base + voffset (column tap, VGPR) + soffset (row tap, SGPR), no per-load
 // address arithmetic.  (Measured alternative, dropped: staging each chunk's residual patch in LDS first
 // -- 61 KB of LDS, 2 blocks per CU, 4 more barriers -- ran 1.7x slower than this.)
+struct FrameOrigins {  // oy, ox of the backward FrameSet: where frame k's 4x4 window starts relative to a padded pixel
+    int oy[SRX_MAX_FRAMES], ox[SRX_MAX_FRAMES];
+};
+
 template <typename T, int F> struct BwdCfg {
     static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, BR = TS + 6 + 2 * R;
     static constexpr int KS = F >= 4 ? 8 : (F == 3 ? 4 : 2);          // frames per chunk
     static constexpr int L = F >= 4 ? 1 : 2;                          // lattice taps per axis
+    static constexpr int PDB = (BR + 3) / F + 3, PLD = PDB | 1;       // LR patch of one frame under a region: edge bound, odd row stride
+    static constexpr int PPT = (PDB * PDB + 255) / 256;               // patch elements per thread
+    static constexpr int RPW = (BR + 3) / 4;                          // region rows per wave
 };
 
 template <typename T, int F, bool SEP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)  // float: three blocks per CU (<= 168 VGPRs)
     k_bwd_tile(const T *__restrict__ err, int h, int w, int N, int KP, const LTap<T, BwdCfg<T, F>::L> *__restrict__ tyT,
                const LTap<T, BwdCfg<T, F>::L> *__restrict__ txT, int H, int W, Kernel7<T> kt, T step, T n,
                const T *__restrict__ hr_in, T *__restrict__ hr_out, const double *__restrict__ epart, int nblk,
-               double *__restrict__ errors, int errors_stride)
+               double *__restrict__ errors, int errors_stride, FrameOrigins fo)
 {
     using C = BwdCfg<T, F>;
-    constexpr int R = C::R, TS = C::TS, BR = C::BR, LD = BR + 1, L = C::L, KS = C::KS;
+    constexpr int R = C::R, TS = C::TS, BR = C::BR, LD = BR + 1, L = C::L, PDB = C::PDB, PLD = C::PLD, PPT = C::PPT, RPW = C::RPW;
     __shared__ T reg[BR * LD];
+    __shared__ T patch[PDB * PLD];
+    __shared__ LTap<T, L> ytab[BR + 3];  // the current frame's row taps, o = patch row offset (row * PLD)
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     int bx, by, b;
@@ -1099,6 +1108,7 @@ __global__ void __launch_bounds__(256)
         __shared__ double part4[4];
         err_trace_reduce(epart, nblk, b, 0.0, errors + (size_t)b * errors_stride, tid, part4);
     }
+    SRX_STAMP(3, 0);
     const int r0 = by * TS, c0 = bx * TS;
     const int pa = max(0, r0 + 9 - R), pb = min(Hp, r0 + TS + 15 + R);
     const int qa = max(0, c0 + 9 - R), qb = min(Wp, c0 + TS + 15 + R);
@@ -1110,80 +1120,112 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int o = 0; o < 8; o++)
             hv[half][o] = hr_in[(size_t)b * H * W + (size_t)min(r0 + half * 32 + wave * 8 + o, H - 1) * W + min(c0 + lane, W - 1)];
-    // ---- gather v: this thread owns region columns lane and lane+64; its wave walks rows wave, wave+4, ...
+    // ---- gather v = sum_k F_k pad(U err_k) on the region.  Frame by frame: the LR residual patch under the region goes to
+    // LDS once (<= PDB^2 samples; the next frame's is prefetched into registers meanwhile) and the L x L lattice taps of
+    // every region pixel read it there.  Read straight from L1/L2 the same taps were 16 loads per pixel at f = 2, N = 4 --
+    // 2256 wave-loads per tile through one texture path shared by three blocks: 79 % of this kernel on a single frame.
+    // This thread owns region columns lane and lane + 64 of the rows wave, wave + 4, ...; sums stay in registers.
     const bool c0ok = lane < nc, c1ok = lane + 64 < nc;
-    const int q0 = qa + (c0ok ? lane : 0), q1 = qa + (c1ok ? lane + 64 : 0);
+    const int q0 = qa + min(lane, nc - 1), q1 = qa + min(lane + 64, nc - 1);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const T *eb = err + (size_t)b * N * h * w;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)eb, 0, (int)((size_t)N * h * w * sizeof(T)), 0x00020000);
-    for (int kc = 0; kc < KP; kc += KS) {
-        T cw0[KS][L], cw1[KS][L];
-        int co0[KS][L], co1[KS][L];
+    T acc0[RPW], acc1[RPW];
 #pragma unroll
-        for (int k = 0; k < KS; k++) {
-            const int kk = min(kc + k, N - 1);  // padding frames: any valid column tap, their row weight is 0
-            const LTap<T, L> t0 = txT[(size_t)kk * Wp + q0], t1 = txT[(size_t)kk * Wp + q1];
+    for (int i = 0; i < RPW; i++)
+        acc0[i] = acc1[i] = 0;
+    int jy0, jx0, npy, npx;  // frame k's patch: LR rows [jy0, jy0 + npy) x columns [jx0, jx0 + npx), block-uniform
+    auto geometry = [&](int k) {
+        const int y_lo = min(max(pa + fo.oy[k] - SRX_NPAD, 0), H - 1), y_hi = min(max(pb + 2 + fo.oy[k] - SRX_NPAD, 0), H - 1);
+        const int x_lo = min(max(qa + fo.ox[k] - SRX_NPAD, 0), W - 1), x_hi = min(max(qb + 2 + fo.ox[k] - SRX_NPAD, 0), W - 1);
+        jy0 = min((y_lo + F - 1) / F, h - 1), jx0 = min((x_lo + F - 1) / F, w - 1);
+        npy = min(max(y_hi / F - jy0 + 1, 1), PDB), npx = min(max(x_hi / F - jx0 + 1, 1), PDB);
+    };
+    T pre[PPT];
+    LTap<T, L> tyn;  // row tap of region row `tid` for the frame being fetched
+    auto fetch = [&](int k) {
+        const T *src = eb + (size_t)k * h * w;
 #pragma unroll
-            for (int q = 0; q < L; q++) {
-                cw0[k][q] = t0.w[q], cw1[k][q] = t1.w[q];
-                co0[k][q] = t0.o[q] * (int)sizeof(T);
-                co1[k][q] = t1.o[q] * (int)sizeof(T);
-            }
+        for (int i = 0; i < PPT; i++) {
+            const int idx = tid + 256 * i, py = idx / PDB, px = idx - py * PDB;
+            pre[i] = src[(size_t)min(jy0 + py, h - 1) * w + min(jx0 + px, w - 1)];
         }
-        // two region rows per trip: 2 x 2 x KS residual reads in flight per lane before the first use
-        for (int rr = uwave; rr < nr; rr += 8) {
-            const int rr2 = min(rr + 4, nr - 1);  // clamped duplicate when there is no second row; dropped below
-            const LTap<T, L> *trow = tyT + (size_t)(pa + rr) * KP + kc;
-            const LTap<T, L> *trow2 = tyT + (size_t)(pa + rr2) * KP + kc;
-            T a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        tyn = tyT[(size_t)(pa + min(tid, nr - 1)) * KP + k];
+    };
+    auto stash = [&]() {  // uses the geometry of the frame that was fetched
 #pragma unroll
-            for (int k = 0; k < KS; k++) {
-                const LTap<T, L> ty = trow[k], ty2 = trow2[k];
+        for (int i = 0; i < PPT; i++) {
+            const int idx = tid + 256 * i, py = idx / PDB, px = idx - py * PDB;
+            if (py < PDB)
+                patch[py * PLD + px] = pre[i];
+        }
+        if (tid < nr) {  // row taps through LDS, not scalar loads: s_load and ds_read share one wait counter, so a scalar
+                         // tap per row drained the whole LDS queue at every row
+            LTap<T, L> t = tyn;
 #pragma unroll
-                for (int m = 0; m < L; m++) {
-                    T s0 = 0, s1 = 0, u0 = 0, u1 = 0;
-                    const int so = (min(kc + k, N - 1) * h + ty.o[m]) * w * (int)sizeof(T);
-                    const int so2 = (min(kc + k, N - 1) * h + ty2.o[m]) * w * (int)sizeof(T);
+            for (int m = 0; m < L; m++)
+                t.o[m] = min(max(t.o[m] - jy0, 0), npy - 1) * PLD;  // a tap outside the patch has weight 0: any cell will do
+            ytab[tid] = t;
+        }
+    };
+    geometry(0);
+    fetch(0);
+    for (int k = 0; k < N; k++) {
+        stash();
+        const int cjx0 = jx0, cnpx = npx;
+        __syncthreads();
+        if (k + 1 < N) {
+            geometry(k + 1);
+            fetch(k + 1);
+        }
+        const LTap<T, L> t0 = txT[(size_t)k * Wp + q0], t1 = txT[(size_t)k * Wp + q1];
+        int x0[L], x1[L];  // patch columns of this lane's taps (a tap outside the patch has weight 0: any cell will do)
 #pragma unroll
-                    for (int q = 0; q < L; q++) {
-                        s0 += cw0[k][q] * buf_load<T>(rs, co0[k][q], so);
-                        s1 += cw1[k][q] * buf_load<T>(rs, co1[k][q], so);
-                        u0 += cw0[k][q] * buf_load<T>(rs, co0[k][q], so2);
-                        u1 += cw1[k][q] * buf_load<T>(rs, co1[k][q], so2);
-                    }
-                    a0 += ty.w[m] * s0;
-                    a1 += ty.w[m] * s1;
-                    b0 += ty2.w[m] * u0;
-                    b1 += ty2.w[m] * u1;
-                }
+        for (int q = 0; q < L; q++)
+            x0[q] = min(max(t0.o[q] - cjx0, 0), cnpx - 1), x1[q] = min(max(t1.o[q] - cjx0, 0), cnpx - 1);
+        LTap<T, L> tyc = ytab[min(uwave, nr - 1)];  // one address per wave: an LDS broadcast
+#pragma unroll
+        for (int i = 0; i < RPW; i++) {
+            // rows past the region are clamped duplicates, dropped at the store; the next row's tap is read before this
+            // row's samples, whose addresses depend on it
+            const LTap<T, L> ty = tyc;
+            if (i + 1 < RPW)
+                tyc = ytab[min(uwave + 4 * (i + 1), nr - 1)];
+            T a0 = 0, a1 = 0;
+#pragma unroll
+            for (int m = 0; m < L; m++) {
+                const T *prow = patch + ty.o[m];
+                T s0 = 0, s1 = 0;
+#pragma unroll
+                for (int q = 0; q < L; q++)
+                    s0 += t0.w[q] * prow[x0[q]], s1 += t1.w[q] * prow[x1[q]];
+                a0 += ty.w[m] * s0;
+                a1 += ty.w[m] * s1;
             }
-            const bool second = rr + 4 < nr;
-            if (kc == 0) {
-                if (c0ok)
-                    reg[rr * LD + lane] = a0;
-                if (c1ok)
-                    reg[rr * LD + lane + 64] = a1;
-                if (second && c0ok)
-                    reg[rr2 * LD + lane] = b0;
-                if (second && c1ok)
-                    reg[rr2 * LD + lane + 64] = b1;
-            } else {
-                if (c0ok)
-                    reg[rr * LD + lane] += a0;
-                if (c1ok)
-                    reg[rr * LD + lane + 64] += a1;
-                if (second && c0ok)
-                    reg[rr2 * LD + lane] += b0;
-                if (second && c1ok)
-                    reg[rr2 * LD + lane + 64] += b1;
-            }
+            acc0[i] += a0;
+            acc1[i] += a1;
+            // pin the sums of every row in place: left alone, hipcc hoists the LDS reads of all RPW rows ahead of the
+            // fmas (196 VGPRs, two blocks per CU)
+            asm volatile("" : "+v"(acc0[i]), "+v"(acc1[i])::"memory");
+        }
+        __syncthreads();  // all taps of frame k read: the patch may be overwritten
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+        const int rr = uwave + 4 * i;
+        if (rr < nr) {
+            if (c0ok)
+                reg[rr * LD + lane] = acc0[i];
+            if (c1ok)
+                reg[rr * LD + lane + 64] = acc1[i];
         }
     }
     __syncthreads();
+    SRX_STAMP(3, 1);
     // rows the 7x7 window of this tile reads: image rows [r0-3, r0+TS+3)
     tile_iir2d<T, 256, LD>(reg, nr, nc, pa == 0, qa == 0, tid, r0 + 9 - pa, min(r0 + TS + 15, Hp) - pa);
+    SRX_STAMP(3, 2);
     zero_outside_image<T, TS, LD>(reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa), r0, c0, H, W, tid);
+    SRX_STAMP(3, 3);
     // ---- 7x7 correlation with the flipped kernel + update
     const T *win = reg + (r0 + 9 - pa) * LD + (c0 + 9 - qa);  // region cell of image (r0-3, c0-3)
     const int c = c0 + lane;
@@ -1205,6 +1247,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    SRX_STAMP(3, 4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1249,6 +1292,9 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL((k_build_ltaps<T, L>), dim3(cdiv(Wp, 64), N), dim3(64), 0, st, txT, Wp, W, w, f, bwd, KP, 1);
     SRX_CHECK_LAUNCH();
+    FrameOrigins fo;
+    for (int k = 0; k < SRX_MAX_FRAMES; k++)
+        fo.oy[k] = k < N ? bwd.f[k].oy : 0, fo.ox[k] = k < N ? bwd.f[k].ox : 0;
     constexpr int TS = TileCfg<T>::T_HR;
     const int tl = TS / f;  // LR tile edge
     const bool sep = kc.separable && kt.separable;
@@ -1264,10 +1310,10 @@ static int ibp_v2_loop(const T *lr, int B, int N, int h, int w, const FrameSet<T
                    omin_x, omax_x, tl, tl, err, errors ? epart : nullptr, scale);
         if (sep)
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, true>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt, (T)step,
-                       (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
+                       (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter, fo);
         else
             SRX_LAUNCH(KID_BWD_TILE, (k_bwd_tile<T, F, false>), wgrid, bblk, 0, st, err, h, w, N, KP, tyT, txT, H, W, kt,
-                       (T)step, (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter);
+                       (T)step, (T)N, cur, hr, epart, (int)(fgrid.x * fgrid.y), errors ? errors + it : nullptr, n_iter, fo);
     }
     return SRX_OK;
 }

@@ -29,23 +29,6 @@
 namespace srx {
 namespace mosaic {
 
-// Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
-// buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
-#ifdef SRX_STAMPS
-__device__ unsigned long long srx_dbg_stamps[3][8][40000];  // [kernel][phase][block]
-#define SRX_STAMP(K, PH)                                                                                       \
-    do {                                                                                                        \
-        if (threadIdx.x == 0 && threadIdx.y == 0) {                                                             \
-            unsigned long long _t;                                                                               \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
-            const unsigned _blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
-            if (_blk < 40000)                                                                                    \
-                srx_dbg_stamps[K][PH][_blk] = _t;                                                                \
-        }                                                                                                       \
-    } while (0)
-#else
-#define SRX_STAMP(K, PH) do { } while (0)
-#endif
 
 #ifndef SRX_FWD_BATCH
 #define SRX_FWD_BATCH 24
