@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import sr_mi355x as S  # noqa: E402
 from sr_mi355x import _lib, synth  # noqa: E402
 
-f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), 1024
+f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), int(os.environ.get("STAMPS_B", "1024"))
 lr = torch.rand((B, 16, 64, 64), device="cuda") * 255
 saa = S.shift_and_add_batched(lr, shifts, f)
 S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
@@ -32,7 +32,7 @@ names = {0: ("k_fwd_mosaic", ["prefetch M,C", "load region + store", "column pas
          2: ("k_saa_tile", ["start", "frame 0 fetch+stash", "frame 0 row pass", "frame 0 column pass", "frame 0 stash next", "frames 1..N-1", "region + walks", "output"])}
 for k, (kn, ph) in names.items():
     t = buf[k].astype(np.int64)
-    nb = 25600 if k == 0 else (768 if k == 3 else 16384)
+    nb = 25 * B if k == 0 else (768 if k == 3 else 16 * B)
     last = len(ph) - 1
     ok = (t[0, :nb] > 0) & (t[last, :nb] > t[0, :nb])
     tot = (t[last, :nb] - t[0, :nb])[ok]
