@@ -23,7 +23,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -52,7 +52,7 @@ static int shift_sampled(const T *in, int B, int H, int W, double sy, double sx,
 {
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     SRX_TRY(pad_edge(in, B, H, W, pad, st));
-    SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
+    SRX_TRY(fused::prefilter2d_fast(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
     if (!taps_ready) {
         SRX_TRY(build_taps(ty, Ho, Hp, TAP_SHIFT, istep, -sy, st));  // scipy negates the shift: cc = i + (-s)
         SRX_TRY(build_taps(tx, Wo, Wp, TAP_SHIFT, istep, -sx, st));
@@ -87,7 +87,7 @@ static int zoom_into(const T *in, size_t in_stride, int B, int h, int w, int Ho,
                      AxisTap<T> *ty, AxisTap<T> *tx, hipStream_t st)
 {
     SRX_TRY(copy_items(in, in_stride, B, (size_t)h * w, coef, st));
-    SRX_TRY(prefilter2d(coef, cscr, B, h, w, MODE_MIRROR, st));
+    SRX_TRY(fused::prefilter2d_fast(coef, cscr, B, h, w, MODE_MIRROR, st));
     const double zy = Ho > 1 ? (double)(h - 1) / (double)(Ho - 1) : 1.0;
     const double zx = Wo > 1 ? (double)(w - 1) / (double)(Wo - 1) : 1.0;
     SRX_TRY(build_taps(ty, Ho, h, TAP_ZOOM, 1, zy, st));

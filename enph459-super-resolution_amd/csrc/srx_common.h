@@ -67,6 +67,7 @@ enum KernelId {
     KID_BWD_MOSAIC,
     KID_SAA_TILE,
     KID_PREFILTER_SMALL,
+    KID_PREFILTER_TILE,
     KID_COUNT
 };
 

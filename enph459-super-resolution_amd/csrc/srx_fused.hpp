@@ -558,6 +558,10 @@ template <> struct TileCfg<double> { static constexpr int R = 23, T_HR = 32; };
 #ifndef SRX_WALK_U
 #define SRX_WALK_U 8
 #endif
+// boundary-condition flags of a walk (default 0 = SciPy 'reflect' at a true array end, what shift(mode='nearest') uses on its
+// pre-padded array): the line starts / ends at a true array end whose condition is 'mirror' (zoom's prefilter)
+#define SRX_BC_MIRROR_LO 1
+#define SRX_BC_MIRROR_HI 2
 template <typename T> struct WalkState {
     T prev;        // causal state p[i-1] = c+[i-1] / 6
     T g0, g1, g2;  // MODE 1: the three newest FIR inputs
@@ -642,7 +646,8 @@ __device__ __forceinline__ void anticausal_run(T *__restrict__ line, int ihi, in
 
 // start of the causal recursion at the beginning of a line
 template <typename T, int S, int MODE>
-__device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, bool edge, WalkState<T> &st, T w0, T w1, T w2, T w3)
+__device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, bool edge, WalkState<T> &st, T w0, T w1, T w2, T w3,
+                                             int bc = 0)
 {
     constexpr int K = Warmup<T>::n;
     const T z = pole<T>();
@@ -653,6 +658,16 @@ __device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, 
         if (MODE == 1)
             v0 = w0 * line[0] + w1 * line[S] + w2 * line[2 * S] + w3 * line[3 * S];
         st.prev = v0 / ((T)1 - z);
+    } else if (MODE == 0 && (bc & SRX_BC_MIRROR_LO)) {
+        // 'mirror' start (whole-sample symmetric, scipy.ndimage.zoom's prefilter): c+[0] = sum_i z^i 6 v[i], so the state
+        // before sample 0 is sum_{i>=1} z^(i-1) v[i]  (lines of >= 64 samples: the far-end terms z^n vanish)
+        T zi = 1, acc = 0;
+        const int kk = min(K + 1, n);
+        for (int i = 1; i < kk; i++) {
+            acc += zi * line[i * S];
+            zi *= z;
+        }
+        st.prev = acc;
     } else {  // exact 'reflect' end of the padded array: c+[0] = 6 v[0] + z * sum_i z^i 6 v[i]
         T zi = 1, acc = 0;
         const int kk = min(K, n);
@@ -675,17 +690,26 @@ __device__ __forceinline__ void causal_begin(const T *__restrict__ line, int n, 
         st.g0 = line[0], st.g1 = line[S], st.g2 = line[2 * S];
 }
 
+// last coefficient of a line from the causal state p[n-1] (= c+[n-1] / 6) and, for 'mirror', q[n-2] = -z c+[n-2] in the line
 template <typename T, int S, int MODE>
-__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w, int need_lo = 0)
+__device__ __forceinline__ T anticausal_end(const T *__restrict__ line, int n, T p_last, int bc)
 {
     const T z = pole<T>();
+    if (MODE == 0 && (bc & SRX_BC_MIRROR_HI) && n >= 2)
+        return ((T)6 * p_last - line[(n - 2) * S]) * (z / (z * z - (T)1));  // (z c+[n-2] + c+[n-1]) z / (z^2 - 1)
+    return p_last * ((T)6 * z / (z - (T)1));
+}
+
+template <typename T, int S, int MODE>
+__device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool edge, const T *__restrict__ w, int need_lo = 0, int bc = 0)
+{
     const int n = MODE == 1 ? n_in - 3 : n_in;
     const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
     WalkState<T> st;
     st.g0 = st.g1 = st.g2 = 0;
-    causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
+    causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3, bc);
     causal_run<T, S, MODE>(line, 0, n, st, w0, w1, w2, w3);
-    st.next = st.prev * ((T)6 * z / (z - (T)1));
+    st.next = anticausal_end<T, S, MODE>(line, n, st.prev, bc);
     st.a1 = st.next, st.a2 = 0, st.a3 = 0;
     if (MODE != 2)
         line[(n - 1) * S] = st.next;
@@ -699,10 +723,10 @@ __device__ __forceinline__ void walk_line(T *__restrict__ line, int n_in, bool e
 // chain, which is what bounds this phase (2 of a block's 4 waves used to walk, 2 idled at the barrier).
 template <typename T, int S, int MODE, int R>
 __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pitch, int nlines, int n_in, bool edge,
-                                               const T *__restrict__ w, int tid, int need_lo = 0)
+                                               const T *__restrict__ w, int tid, int need_lo = 0, int bc = 0)
 {
     constexpr int O = MODE == 1 ? 3 : 0;
-    const T z = pole<T>(), zfin = z / (z - (T)1), kq = (T)-6 * z;
+    const T z = pole<T>(), kq = (T)-6 * z;
     const int n = MODE == 1 ? n_in - 3 : n_in;
     const T w0 = MODE ? w[0] : (T)0, w1 = MODE ? w[1] : (T)0, w2 = MODE ? w[2] : (T)0, w3 = MODE ? w[3] : (T)0;
     const int lineid = tid & 127, seg = tid >> 7;
@@ -710,7 +734,7 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     T *line = base + (active ? lineid : 0) * line_pitch;
     if (n < 4 * R + 16) {  // too short to split (block-uniform): one thread per line
         if (active && seg == 0)
-            walk_line<T, S, MODE>(line, n_in, edge, w, need_lo);
+            walk_line<T, S, MODE>(line, n_in, edge, w, need_lo, bc);
         __syncthreads();
         return;
     }
@@ -737,7 +761,7 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     // ---- B: causal ----
     if (active) {
         if (seg == 0) {
-            causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3);
+            causal_begin<T, S, MODE>(line, n, edge, st, w0, w1, w2, w3, bc);
             causal_run<T, S, MODE>(line, 0, mid - 8, st, w0, w1, w2, w3);
             // last 8 outputs: for MODE 1 the three newest FIR inputs come from registers
             T x[8];
@@ -788,7 +812,7 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     // ---- D: anticausal ----
     if (active) {
         if (seg == 1) {
-            st.next = st.prev * ((T)6 * zfin);
+            st.next = anticausal_end<T, S, MODE>(line, n, st.prev, bc);
             st.a1 = st.next, st.a2 = 0, st.a3 = 0;
             if (MODE != 2)
                 line[(n - 1) * S] = st.next;
@@ -918,13 +942,62 @@ __device__ __forceinline__ void walk_pass_4seg(T *__restrict__ base, int line_pi
 
 // in-place 2-D prefilter of an LDS region [nr x nc], row stride LD (odd: conflict-free row walks).
 // Axis 0 runs over all nc columns; axis 1 only over rows [r_lo, r_hi) (the rows a consumer reads).
-template <typename T, int NT, int LD>
+template <typename T, int NT, int LD, int RW = TileCfg<T>::R>
 __device__ __forceinline__ void tile_iir2d(T *reg, int nr, int nc, bool top_edge, bool left_edge, int tid, int r_lo,
-                                           int r_hi)
+                                           int r_hi, int bc_y = 0, int bc_x = 0)
 {
     static_assert(NT == 256, "walk_pass_2seg assumes a 256-thread block");
-    walk_pass_2seg<T, LD, 0, TileCfg<T>::R>(reg, 1, nc, nr, top_edge, nullptr, tid);
-    walk_pass_2seg<T, 1, 0, TileCfg<T>::R>(reg + r_lo * LD, LD, r_hi - r_lo, nc, left_edge, nullptr, tid);
+    walk_pass_2seg<T, LD, 0, RW>(reg, 1, nc, nr, top_edge, nullptr, tid, 0, bc_y);
+    walk_pass_2seg<T, 1, 0, RW>(reg + r_lo * LD, LD, r_hi - r_lo, nc, left_edge, nullptr, tid, 0, bc_x);
+}
+
+// spline_filter(order 3) of whole planes [B, Hc, Wc] (Hc, Wc >= 64), out of place: one block per 64 x 64 tile, the tile
+// plus WU = Warmup<T>::n samples of halo on every side in LDS, both axes in one launch (tile_iir2d), SciPy's boundary
+// condition (mode: MODE_MIRROR = zoom's prefilter, MODE_REFLECT = shift's on its pre-padded array) where the region
+// touches an array end.  Replaces k_prefilter_axis0 + k_prefilter_axis1 for float planes: those walk whole lines with 64
+// threads per block and a barrier per 64 samples (114 us for four 768 x 1024 frames; this: one read + one write).
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_prefilter_tile(const T *__restrict__ src_, T *__restrict__ dst_, int Hc, int Wc, int mode)
+{
+    constexpr int TSP = 64, WU = Warmup<T>::n, FR = TSP + 2 * WU, LD = FR | 1;
+    __shared__ T reg[FR * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int r0 = by * TSP, c0 = bx * TSP;
+    const int pa = max(0, r0 - WU), pb = min(Hc, r0 + TSP + WU), qa = max(0, c0 - WU), qb = min(Wc, c0 + TSP + WU);
+    const int nr = pb - pa, nc = qb - qa;
+    const T *src = src_ + (size_t)b * Hc * Wc;
+    load_region<T, FR, FR, 13>(reg, LD, src + (size_t)pa * Wc + qa, Wc, nr, nc, wave, lane);
+    __syncthreads();
+    const bool mirror = mode == 0;  // MODE_MIRROR (srx_prims.hpp)
+    const int bc_y = mirror ? ((pa == 0 ? SRX_BC_MIRROR_LO : 0) | (pb == Hc ? SRX_BC_MIRROR_HI : 0)) : 0;
+    const int bc_x = mirror ? ((qa == 0 ? SRX_BC_MIRROR_LO : 0) | (qb == Wc ? SRX_BC_MIRROR_HI : 0)) : 0;
+    const int r_lo = r0 - pa, r_hi = min(r0 + TSP, Hc) - pa;
+    tile_iir2d<T, 256, LD, WU>(reg, nr, nc, pa == 0, qa == 0, tid, r_lo, r_hi, bc_y, bc_x);
+    T *dst = dst_ + (size_t)b * Hc * Wc;
+    for (int idx = tid; idx < TSP * TSP; idx += 256) {
+        const int r = r0 + idx / TSP, c = c0 + idx % TSP;
+        if (r < Hc && c < Wc)
+            dst[(size_t)r * Wc + c] = reg[(r - pa) * LD + (c - qa)];
+    }
+}
+
+// spline_filter(order 3) of a [B, Hc, Wc] stack in place (through `scratch`): the tile kernel for float planes of at least
+// 64 x 64, the line kernels of srx_prims.hpp otherwise
+template <typename T> static int prefilter2d_fast(T *a, T *scratch, int B, int Hc, int Wc, int mode, hipStream_t st)
+{
+    if constexpr (sizeof(T) == 4) {  // (the double tile would not fit the LDS)
+        if (Hc >= 64 && Wc >= 64 && B <= 65535 && !getenv("SRX_NO_PREFILTER_TILE")) {
+            SRX_LAUNCH(KID_PREFILTER_TILE, k_prefilter_tile<T>, dim3(cdiv(Wc, 64), cdiv(Hc, 64), B), dim3(256), 0, st, a, scratch, Hc, Wc,
+                       mode);
+            if (hipMemcpyAsync(a, scratch, (size_t)B * Hc * Wc * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return SRX_E_HIP;
+            return SRX_OK;
+        }
+    }
+    return prefilter2d(a, scratch, B, Hc, Wc, mode, st);
 }
 
 // FWD: err[b,k,i,j] = lr[b,k,i,j] - (F_k P bpad)[f i, f j];  errors[b] += sum err^2 * scale.
@@ -1365,13 +1438,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
         SRX_LAUNCH(KID_BLUR_PAD, (k_blur_pad<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
-        SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
+        SRX_TRY(prefilter2d_fast(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
         SRX_LAUNCH(KID_FWD_RESIDUAL, k_fwd_residual<T>, dim3(cdiv(w, 16), cdiv(h, 16), B), dim3(16, 16),
                    (size_t)th * tw * sizeof(T), st, pad, Hp, Wp, lr, h, w, f, fwd, omin_y, omin_x, th, tw, err,
                    errors ? errors + it : nullptr, n_iter, scale);
         SRX_LAUNCH(KID_BACK_GATHER, k_back_gather<T>, dim3(cdiv(Wp, 64), cdiv(Hp, 4), B), dim3(64, 4), 0, st, err, h, w, f,
                    bwd, H, W, pad);
-        SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
+        SRX_TRY(prefilter2d_fast(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
         SRX_LAUNCH(KID_BLURT_UPDATE, (k_blurT_update<T, false>), bgrid, bblk, 0, st, pad, H, W, kt, (T)step, (T)N, cur, hr);
     }
     return SRX_OK;
@@ -1402,7 +1475,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
     // spline coefficients of every LR frame at once: [B*N, h, w], 'mirror' ends (scipy.ndimage.zoom)
     if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SRX_E_HIP;
-    SRX_TRY(prefilter2d(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+    SRX_TRY(prefilter2d_fast(coef, cscr, B * N, h, w, MODE_MIRROR, st));
     const double zy_ = H > 1 ? (double)(h - 1) / (double)(H - 1) : 1.0;
     const double zx_ = W > 1 ? (double)(w - 1) / (double)(W - 1) : 1.0;
     SRX_TRY(build_taps(zy, H, h, TAP_ZOOM, 1, zy_, st));
@@ -1417,7 +1490,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         else
             SRX_LAUNCH(KID_FIR_PAD, (k_fir_pad<T, true>), grd, blk, 0, st, up, H, W, ft, pad);
     }
-    SRX_TRY(prefilter2d(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
+    SRX_TRY(prefilter2d_fast(pad, scr, B, Hp, Wp, MODE_REFLECT, st));
     SRX_LAUNCH(KID_CROP_DIV, k_crop_div<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, pad, H, W, (T)N, out);
     return SRX_OK;
 }
