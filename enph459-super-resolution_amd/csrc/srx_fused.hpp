@@ -732,7 +732,8 @@ __device__ __forceinline__ void walk_pass_2seg(T *__restrict__ base, int line_pi
     const int lineid = tid & 127, seg = tid >> 7;
     const bool active = lineid < nlines;
     T *line = base + (active ? lineid : 0) * line_pitch;
-    if (n < 4 * R + 16) {  // too short to split (block-uniform): one thread per line
+    // the cut needs R <= mid <= n - R with mid a multiple of 8 (and 8 outputs before it for MODE 1's register tail)
+    if (((R + 7) & ~7) > ((n - R) & ~7)) {  // too short to split (block-uniform): one thread per line
         if (active && seg == 0)
             walk_line<T, S, MODE>(line, n_in, edge, w, need_lo, bc);
         __syncthreads();
