@@ -366,7 +366,7 @@ int srx_debug_stamps(unsigned long long *host_out)
 {
     if (hipDeviceSynchronize() != hipSuccess)
         return SRX_E_HIP;
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(srx::srx_dbg_stamps), sizeof(unsigned long long) * 4 * 8 * 40000) != hipSuccess)
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(srx::srx_dbg_stamps), sizeof(unsigned long long) * 5 * 8 * 40000) != hipSuccess)
         return SRX_E_HIP;
     return SRX_OK;
 }

@@ -158,7 +158,7 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
 // Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
 // buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
 #ifdef SRX_STAMPS
-__device__ unsigned long long srx_dbg_stamps[4][8][40000];  // [kernel][phase][block]
+__device__ unsigned long long srx_dbg_stamps[5][8][40000];  // [kernel][phase][block]
 #define SRX_STAMP(K, PH)                                                                                       \
     do {                                                                                                        \
         if (threadIdx.x == 0 && threadIdx.y == 0) {                                                             \

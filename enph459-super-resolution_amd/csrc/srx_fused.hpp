@@ -1021,10 +1021,13 @@ __global__ void __launch_bounds__(256)
     const int qa = max(0, f * j0 + omin_x - R), qb = min(Wp - 1, f * (j1 - 1) + omax_x + 3 + R);
     const int nr = pb - pa + 1, nc = qb - qa + 1;
     const int H = Hp - 2 * SRX_NPAD, W = Wp - 2 * SRX_NPAD;
+    SRX_STAMP(4, 0);
     load_region_pad<T, FR, FR>(reg, LD, bimg + (size_t)b * H * W, H, W, pa, qa, nr, nc, wave, lane);
     __syncthreads();
+    SRX_STAMP(4, 1);
     // rows the 4x4 taps of this tile's LR pixels read
     tile_iir2d<T, 256, LD>(reg, nr, nc, pa == 0, qa == 0, tid, f * i0 + omin_y - pa, f * (i1 - 1) + omax_y + 4 - pa);
+    SRX_STAMP(4, 2);
     const int N = fs.n;
     double sq = 0.0;
     for (int idx = tid; idx < th * tw; idx += 256) {
@@ -1050,12 +1053,14 @@ __global__ void __launch_bounds__(256)
             sq += (double)e * (double)e;
         }
     }
+    SRX_STAMP(4, 3);
     sq = wave_sum(sq);
     if (lane == 0)
         part[wave] = sq;
     __syncthreads();
     if (tid == 0 && epart)  // this tile's share of the MSE trace; summed by k_bwd_tile (err_trace_reduce)
         epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+    SRX_STAMP(4, 4);
 }
 
 // Per (frame, padded coordinate) lattice taps of the back-projection gather: the <= L LR samples

@@ -22,17 +22,18 @@ S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
 lr1 = torch.rand((1, 4, 768, 1024), device="cuda") * 255
 saa1 = S.shift_and_add_batched(lr1, synth.MEASURED_4, 2)
 S.ibp_batched(lr1, synth.MEASURED_4, synth.asymmetric_psf(), saa1, 2, 3, 0.5)
-buf = np.zeros((4, 8, 40000), dtype=np.uint64)
+buf = np.zeros((5, 8, 40000), dtype=np.uint64)
 lib = _lib.load()
 lib.srx_debug_stamps.argtypes = [ctypes.c_void_p]
 assert lib.srx_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 names = {0: ("k_fwd_mosaic", ["prefetch M,C", "load region + store", "column pass", "row pass", "pixel phase", "reduce+atomic"]),
          1: ("k_bwd_mosaic", ["prefetch hr", "load region + store", "column pass", "row pass", "zero border", "blur+update"]),
+         4: ("k_fwd_tile (one 1536x2048 frame)", ["start", "load region", "prefilter 2-D", "taps + residuals", "reduce"]),
          3: ("k_bwd_tile (one 1536x2048 frame)", ["start", "gather", "prefilter 2-D", "zero strips", "7x7 + update"]),
          2: ("k_saa_tile", ["start", "frame 0 fetch+stash", "frame 0 row pass", "frame 0 column pass", "frame 0 stash next", "frames 1..N-1", "region + walks", "output"])}
 for k, (kn, ph) in names.items():
     t = buf[k].astype(np.int64)
-    nb = 25 * B if k == 0 else (768 if k == 3 else 16 * B)
+    nb = 25 * B if k == 0 else (768 if k >= 3 else 16 * B)
     last = len(ph) - 1
     ok = (t[0, :nb] > 0) & (t[last, :nb] > t[0, :nb])
     tot = (t[last, :nb] - t[0, :nb])[ok]
