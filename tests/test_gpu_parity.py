@@ -426,3 +426,29 @@ def test_randomised_parity_sweep():
         assert fz.run(80, seed=459) == 0
     finally:
         S.set_precision("f32")
+
+
+def test_batches_beyond_one_launch():
+    """Batches larger than one launch's gridDim.z are split inside the library (srx_api.hip: chunks of 32768 items, or of
+    32768 // N for shift_and_add's frame stacks; the workspace is sized for one chunk).  Items on both sides of a chunk
+    boundary equal the same item computed alone."""
+    S.set_precision("f32")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(21)
+    # shift_and_add: B * N = 2100 * 16 > 32768 -> chunks of 2048 items
+    f, shifts = 4, synth.phase_shifts(4)
+    lr = torch.round(torch.rand((2100, 16, 8, 8), generator=gen, device="cuda") * 255)
+    saa = S.shift_and_add_batched(lr, shifts, f)
+    for i in (0, 2047, 2048, 2099):
+        assert torch.equal(saa[i], S.shift_and_add_batched(lr[i:i + 1], shifts, f)[0])
+    # ibp: B = 33000 > 32768
+    f2, sh2, psf = 2, [(0.5, -0.5), (-0.5, 0.5)], synth.gaussian_psf()
+    lr2 = torch.round(torch.rand((33000, 2, 16, 16), generator=gen, device="cuda") * 255)
+    init = S.shift_and_add_batched(lr2, sh2, f2)
+    hr, errs = S.ibp_batched(lr2, sh2, psf, init, f2, 3, 0.5)
+    path = S.last_path()
+    for i in (0, 32767, 32768, 32999):
+        h1, e1 = S.ibp_batched(lr2[i:i + 1], sh2, psf, init[i:i + 1], f2, 3, 0.5)
+        assert S.last_path() == path
+        assert torch.equal(hr[i], h1[0])
+        np.testing.assert_allclose(errs[i].cpu().numpy(), e1[0].cpu().numpy(), rtol=1e-12)
