@@ -493,6 +493,138 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------
+// FWD for delta = 0 on both axes, blur included: Y[P, Q] = (B hr)[clamp(P - 11), clamp(Q - 11)] is a pure index map, so the
+// forward kernel can own IMAGE tiles (32 x 64, as k_blur_pad), blur them from hr and write G without the blurred plane ever
+// going to memory (it was a 4 B write + 4 B read per HR pixel and a launch per iteration).  G pixel (pg, qg) belongs to the
+// tile that holds image pixel (clamp(pg - 13), clamp(qg - 13)): the tile's own 32 x 64 pixels map one to one (their blurred
+// values stay in registers); the rows / columns of G beyond the image (pg < 13: near band; pg >= H + 13: far field with an
+// edge-replicated Y) belong to the edge tiles, which stage their blurred values in LDS and walk those pixels in a second
+// loop together with the near band of k_fwd_mosaic.  grid (ceil(W/64), ceil(H/32), B), block (64, 4).
+// ---------------------------------------------------------------------------------------
+template <typename T, bool SEP>
+__global__ void __launch_bounds__(256)
+    k_blurfwd_zero(const T *__restrict__ hr, int H, int W, Kernel7<T> ka, const T *__restrict__ Mg, const T *__restrict__ Cg, int Hg,
+                   int Wg, MosaicArgs<T> ma, const T *__restrict__ Mu, const int *__restrict__ ncu, const int *__restrict__ nyx,
+                   int NS, int NB, T *__restrict__ G, double *__restrict__ epart, double scale)
+{
+    __shared__ T tile[(SRX_BT_H + 6) * SRX_BT_LDW];
+    __shared__ double part[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int c0 = bx * SRX_BT_W, r0 = by * SRX_BT_H;
+    const int uy = __builtin_amdgcn_readfirstlane(ty);
+    // far-field operands of this thread's 8 one-to-one pixels (G row = image row + 13), fetched up front
+    const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(Cg, (size_t)Hg * Wg);
+    const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(Mg + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+    const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(G + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+    const int qg = c0 + tx + 13, vq = min(qg, Wg - 1) * (int)sizeof(T);
+    T Cv[8], Mv[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const int so = min(r0 + uy * 8 + o + 13, Hg - 1) * Wg * (int)sizeof(T);
+        Cv[o] = fused::buf_load<T>(rsC, vq, so);
+        Mv[o] = fused::buf_load<T>(rsM, vq, so);
+    }
+    {
+        // (32+6) x (64+6) source tile, zero outside the image (k_blur_pad's loader)
+        constexpr int RPW = (SRX_BT_H + 6 + 3) / 4;
+        const __amdgpu_buffer_rsrc_t rs = fused::plane_rsrc(hr + (size_t)b * H * W, (size_t)H * W);
+        const int ca = c0 - 3 + tx, cb = c0 + 61 + (tx & 7);
+        const int va = min(max(ca, 0), W - 1) * (int)sizeof(T), vb = min(max(cb, 0), W - 1) * (int)sizeof(T);
+        const bool ina = ca >= 0 && ca < W, inb = cb >= 0 && cb < W;
+        T v[RPW][2];
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int so = min(max(r0 - 3 + uy + 4 * j, 0), H - 1) * W * (int)sizeof(T);
+            v[j][0] = fused::buf_load<T>(rs, va, so);
+            v[j][1] = fused::buf_load<T>(rs, vb, so);
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int sr = uy + 4 * j, r = r0 - 3 + sr;
+            if (sr < SRX_BT_H + 6) {
+                const bool rin = r >= 0 && r < H;
+                tile[sr * SRX_BT_LDW + tx] = (rin && ina) ? v[j][0] : (T)0;
+                if (tx < 6)
+                    tile[sr * SRX_BT_LDW + 64 + tx] = (rin && inb) ? v[j][1] : (T)0;
+            }
+        }
+    }
+    __syncthreads();
+    T acc[8];
+    corr7_strip8<T, SRX_BT_LDW, SEP>(tile, tx, ty, ka, acc);
+    T sqt = 0;
+    // ---- one-to-one pixels that are far field
+    const bool cin = c0 + tx < W, qfar = qg >= ma.PBx;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const int r = r0 + uy * 8 + o, pg = r + 13;
+        if (r < H && cin && qfar && pg >= ma.PBy) {
+            const T g = Cv[o] > (T)0 ? Mv[o] - Cv[o] * acc[o] : (T)0;
+            sqt += g * g * rcp_count(Cv[o]);
+            fused::buf_store<T>(g, rsG, qg * (int)sizeof(T), pg * Wg * (int)sizeof(T));
+        }
+    }
+    // ---- edge tiles: the G rows / columns beyond the image that map to this tile's edge pixels, and the near band
+    const bool top = r0 == 0, left = c0 == 0, bottom = r0 + SRX_BT_H >= H, right = c0 + SRX_BT_W >= W;
+    if (top || left || bottom || right) {  // block-uniform
+        __syncthreads();  // all of corr7's reads of the tile are done: reuse it for the blurred values
+        T *bt = tile;     // bt[ir - r0][ic - c0], row stride 64
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            bt[(ty * 8 + o) * 64 + tx] = acc[o];
+        __syncthreads();
+        auto Yb = [&](int P, int Q) -> T {  // Y[P, Q] for coordinates whose image pixel lies in this tile
+            const int ir = min(max(P - 11, 0), H - 1) - r0, ic = min(max(Q - 11, 0), W - 1) - c0;
+            return bt[min(max(ir, 0), SRX_BT_H - 1) * 64 + min(max(ic, 0), SRX_BT_W - 1)];
+        };
+        const int gr_lo = top ? ma.RSy : r0 + 13, gr_hi = bottom ? Hg : r0 + SRX_BT_H + 13;
+        const int gc_lo = left ? ma.RSx : c0 + 13, gc_hi = right ? Wg : c0 + SRX_BT_W + 13;
+        const int gw = max(gc_hi - gc_lo, 1), total = max(gr_hi - gr_lo, 0) * gw;
+        const T *Mgb = Mg + (size_t)b * Hg * Wg, *Mub = Mu + (size_t)b * NB;
+        T *Gb = G + (size_t)b * Hg * Wg;
+        const int4 *nyx4 = reinterpret_cast<const int4 *>(nyx);
+        const int NS4 = NS >> 2;
+        for (int t = tid; t < total; t += 256) {
+            const int rr = t / gw, pg = gr_lo + rr, qn = gc_lo + t - rr * gw;
+            const bool far = pg >= ma.PBy && qn >= ma.PBx;
+            const bool own = pg - 13 >= r0 && pg - 13 < min(r0 + SRX_BT_H, H) && qn - 13 >= c0 && qn - 13 < min(c0 + SRX_BT_W, W);
+            if (far && own)
+                continue;  // done from registers above
+            const int gi = pg * Wg + qn;
+            if (far) {  // beyond the bottom / right image edge: Y is the edge pixel's
+                const T C = Cg[gi];
+                const T g = C > (T)0 ? Mgb[gi] - C * Yb(pg - ma.Dy, qn - ma.Dx) : (T)0;
+                sqt += g * g * rcp_count(C);
+                Gb[gi] = g;
+                continue;
+            }
+            const int ni = near_index(pg, qn, Wg, ma.PBy, ma.PBx), pk = ncu[ni], cnt = pk & 255, cu = pk >> 8;
+            T ys = 0;
+            for (int e0 = 0; e0 < cnt; e0 += 4) {
+                const int4 c = nyx4[(size_t)ni * NS4 + (e0 >> 2)];
+                const int ce[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    ys += e0 + e < cnt ? Yb(ce[e] & 0xffff, ce[e] >> 16) : (T)0;
+            }
+            Gb[gi] = Mgb[gi] - ys;
+            if (cu > 0) {
+                const T gu = Mub[ni] - (T)cu * Yb(max(pg - ma.Dy, 0), max(qn - ma.Dx, 0));
+                sqt += gu * gu * rcp_count((T)cu);
+            }
+        }
+    }
+    const double sq = wave_sum((double)sqt);
+    if (tx == 0)
+        part[ty] = sq;
+    __syncthreads();
+    if (tid == 0 && epart)
+        epart[((size_t)b * gridDim.y + by) * gridDim.x + bx] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+}
+
+// ---------------------------------------------------------------------------------------
 // BWD: hr = clip(hr + step * B'( crop P FIR_b G ) / n).  grid (ceil(W/T), ceil(H/T), B), block (64, 4).
 //   ZERO: P FIR_b G [p] = G[p + 1] (interpolation condition) -> B' reads G directly.
 // ---------------------------------------------------------------------------------------
@@ -960,14 +1092,25 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     const size_t dbg_lds = getenv("SRX_DBG_LDS") ? (size_t)atoi(getenv("SRX_DBG_LDS")) : 0;  // extra LDS: caps blocks per CU
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, zero ? FwdRows<T, true>::v : TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
+    // delta = 0: blur and forward map in one kernel over image tiles (no blurred plane); SRX_NO_ZERO_FUSE keeps the two kernels
+    const bool zfuse = zero && !getenv("SRX_NO_ZERO_FUSE");
+    const int nblk = zfuse ? (int)(bgrid.x * bgrid.y) : (int)(fgrid.x * fgrid.y);  // MSE partial sums per item
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
         double *eo = errors ? errors + it : nullptr, *ep = errors ? epart : nullptr;
-        if (sep)
+        if (zfuse) {
+            if (sep)
+                SRX_LAUNCH(KID_FWD_MOSAIC, (k_blurfwd_zero<T, true>), bgrid, bblk, 0, st, cur, H, W, kc, Mg, Cg, Hg, Wg, ma, Mu, ncu, nyx, NS,
+                           NB, G, ep, scale);
+            else
+                SRX_LAUNCH(KID_FWD_MOSAIC, (k_blurfwd_zero<T, false>), bgrid, bblk, 0, st, cur, H, W, kc, Mg, Cg, Hg, Wg, ma, Mu, ncu, nyx, NS,
+                           NB, G, ep, scale);
+        } else if (sep)
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, true, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
         else
             SRX_LAUNCH(KID_BLUR_PAD, (fused::k_blur_pad<T, false, false>), bgrid, bblk, 0, st, cur, H, W, kc, pad);
-        if (zero)
+        if (zfuse) {
+        } else if (zero)
             SRX_LAUNCH(KID_FWD_MOSAIC, (k_fwd_mosaic<T, true>), fgrid, dim3(256), 0, st, pad, Hp, Wp, Mg, Cg, Hg, Wg, ma, Mu, ncu,
                        nyx, NS, NB, G, ep, scale, dbg);
         else
@@ -975,7 +1118,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        Mu, ncu, nyx, NS, NB, G, ep, scale, dbg);
 #define SRX_BWDM(Z_, S_)                                                                                             \
     SRX_LAUNCH(KID_BWD_MOSAIC, (k_bwd_mosaic<T, Z_, S_>), wgrid, bblk, dbg_lds, st, G, Hg, Wg, ma, H, W, kt, (T)step, (T)N, cur, hr, \
-               epart, (int)(fgrid.x * fgrid.y), Vtot, scale, eo, n_iter, dbg)
+               epart, nblk, Vtot, scale, eo, n_iter, dbg)
         if (zero) {
             if (sep)
                 SRX_BWDM(true, true);
