@@ -452,3 +452,23 @@ def test_batches_beyond_one_launch():
         assert S.last_path() == path
         assert torch.equal(hr[i], h1[0])
         np.testing.assert_allclose(errs[i].cpu().numpy(), e1[0].cpu().numpy(), rtol=1e-12)
+
+
+def test_delta_zero_fused_forward_matches_two_kernel_form(prec):
+    """delta = 0 (the reference's nominal +-0.5 px at f = 2): the forward kernel that blurs its own image tiles
+    (k_blurfwd_zero) against blur + index-map kernels (SRX_NO_ZERO_FUSE=1), on an image with ragged edge tiles."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    dt = torch.float64 if prec == "f64" else torch.float32
+    lr = torch.round(torch.rand((3, 5, 75, 131), generator=gen, device="cuda", dtype=dt) * 255)
+    init = S.shift_and_add_batched(lr, synth.NOMINAL_5, 2)
+    for psf in (synth.gaussian_psf(), synth.asymmetric_psf()):
+        hr_a, e_a = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5)
+        assert S.last_path() == "mosaic"
+        os.environ["SRX_NO_ZERO_FUSE"] = "1"
+        try:
+            hr_b, e_b = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5)
+        finally:
+            del os.environ["SRX_NO_ZERO_FUSE"]
+        assert float((hr_a - hr_b).abs().max()) <= (1e-10 if prec == "f64" else 2e-4)
+        np.testing.assert_allclose(e_a.cpu().numpy(), e_b.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)
