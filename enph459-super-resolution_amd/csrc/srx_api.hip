@@ -7,6 +7,7 @@
 #include "srx_prims.hpp"
 #include "srx_fused.hpp"
 #include "srx_mosaic.hpp"
+#include "srx_patch.hpp"
 
 using namespace srx;
 
@@ -23,7 +24,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -311,7 +312,7 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
         if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
-            g_last_path = "mosaic";
+            g_last_path = patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f) ? "patch" : "mosaic";
             return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
         }
         g_last_path = "fused";

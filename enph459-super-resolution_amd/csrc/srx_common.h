@@ -68,6 +68,7 @@ enum KernelId {
     KID_SAA_TILE,
     KID_PREFILTER_SMALL,
     KID_PREFILTER_TILE,
+    KID_IBP_PATCH,
     KID_COUNT
 };
 

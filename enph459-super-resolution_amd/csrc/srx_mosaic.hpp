@@ -28,6 +28,16 @@
 
 namespace srx {
 namespace mosaic {
+struct AxisPlan;
+}
+namespace patch {  // srx_patch.hpp: the patch-resident iteration (one workgroup per 256 x 256 HR patch)
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, float *Mt, float *Ct, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st);
+}  // namespace patch
+namespace mosaic {
 
 
 #ifndef SRX_FWD_BATCH
@@ -1087,6 +1097,14 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
+    if constexpr (sizeof(T) == 4) {
+        // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp).
+        // Its transposed far-field operands take the places of the planes it does not need (G and the blurred plane).
+        if (patch::eligible(4, N, H, W, sh, k, kh, kw, f)) {
+            return patch::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, G, pad, n_iter, step, scale,
+                                  errors, st);
+        }
+    }
     constexpr int TS = TileCfg<T>::T_HR;
     const int dbg = getenv("SRX_DBG") ? atoi(getenv("SRX_DBG")) : 0;  // timing ablations only (results are wrong)
     const size_t dbg_lds = getenv("SRX_DBG_LDS") ? (size_t)atoi(getenv("SRX_DBG_LDS")) : 0;  // extra LDS: caps blocks per CU
