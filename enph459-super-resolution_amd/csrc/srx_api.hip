@@ -371,6 +371,14 @@ int srx_debug_stamps(unsigned long long *host_out)
         return SRX_E_HIP;
     return SRX_OK;
 }
+int srx_debug_pstamps(unsigned long long *host_out)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return SRX_E_HIP;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(srx::srx_dbg_pstamps), sizeof(unsigned long long) * 24 * 4096) != hipSuccess)
+        return SRX_E_HIP;
+    return SRX_OK;
+}
 #endif
 
 const char *srx_strerror(int s)

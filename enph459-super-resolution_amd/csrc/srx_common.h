@@ -170,8 +170,21 @@ __device__ unsigned long long srx_dbg_stamps[5][8][40000];  // [kernel][phase][b
                 srx_dbg_stamps[K][PH][_blk] = _t;                                                                \
         }                                                                                                       \
     } while (0)
+// the patch-resident kernel: lane 0 of EVERY wave (16 per block), first 256 blocks: [phase][block * 16 + wave]
+__device__ unsigned long long srx_dbg_pstamps[24][4096];
+#define SRX_PSTAMP(PH)                                                                                         \
+    do {                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {                                                      \
+            unsigned long long _t;                                                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
+            srx_dbg_pstamps[PH][blockIdx.x * 16 + (threadIdx.x >> 6)] = _t;                                      \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
 #else
 #define SRX_STAMP(K, PH) do { } while (0)
+#define SRX_PSTAMP(PH) do { } while (0)
 #endif
 
 // MSE trace without atomics.  Every block of a forward kernel stores its partial sum at epart[item * nblk + tile] (tile =

@@ -32,10 +32,11 @@ struct AxisPlan;
 }
 namespace patch {  // srx_patch.hpp: the patch-resident iteration (one workgroup per 256 x 256 HR patch)
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
-static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+static inline size_t tabs_bytes(int B, int N);
+static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
-                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, float *Mt, float *Ct, int n_iter, double step,
-                   double scale, double *errors, hipStream_t st);
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int n_iter, double step, double scale,
+                   double *errors, hipStream_t st);
 }  // namespace patch
 namespace mosaic {
 
@@ -1028,7 +1029,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
     return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
            align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
            align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int)) +
-           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
+           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double)) +
+           (eb == 4 && H == 256 && W == 256 ? patch::tabs_bytes(B, N) : 0);  // srx_patch.hpp's tables
 }
 
 template <typename T>
@@ -1101,7 +1103,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp).
         // Its transposed far-field operands take the places of the planes it does not need (G and the blurred plane).
         if (patch::eligible(4, N, H, W, sh, k, kh, kw, f)) {
-            return patch::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, G, pad, n_iter, step, scale,
+            return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
                                   errors, st);
         }
     }

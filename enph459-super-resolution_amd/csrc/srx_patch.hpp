@@ -29,6 +29,9 @@
 namespace srx {
 namespace patch {
 
+#ifndef SRX_PATCH_DBG
+#define SRX_PATCH_DBG 0  // timing ablations of a development build only (results are wrong): 1 no M/C loads, 2 no hr re-read,
+#endif                   // 4 no near band, 8 no hr store, 16 no hr load
 constexpr int PN = 256;        // patch edge (HR pixels)
 constexpr int TSD = 66;        // LDS row stride of a half-block transpose (even: 8-byte row reads, conflict-free)
 constexpr int RW = 32 * TSD;   // LDS words of a wave's private region
@@ -58,20 +61,47 @@ struct ZPow {
 };
 __device__ constexpr ZPow ZP{};  // ZP.v[i] = z^(i+1)
 
+typedef float f8 __attribute__((ext_vector_type(8)));
+// Filter weights of one axis.  They live in device memory and are fetched with scalar loads right where a stage needs them
+// (sload8): as by-value kernel arguments the two sets would sit in ~50 scalar registers for the whole iteration loop.
+struct AxisW {
+    float kb[8];  // forward blur (correlation) weights [0..6], times kq = -6 z: the recursions run in the scaled form of srx_fused.hpp
+    float kt[8];  // backward blur (flipped kernel) weights [0..6]
+    float wfb[8]; // [0..3] forward FIR (after the prefilter); [4..7] backward FIR (before the prefilter), times kq
+};
 struct AxisC {
-    float kb[7];  // forward blur (correlation) weights, times kq = -6 z: the recursions run in the scaled form of srx_fused.hpp
-    float kt[7];  // backward blur (flipped kernel) weights
-    float wf[4];  // forward FIR (after the prefilter)
-    float wb[4];  // backward FIR (before the prefilter), times kq
     int ex;       // n_max: G / Y samples above the block grid (0 or 1)
     int nb;       // -n_min: near-band samples inside the grid
     int E;        // padded Y index = rho + E
 };
+__device__ __forceinline__ f8 sload8(const float *p)
+{
+    f8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+constexpr int NN_PAD = 2048;  // near-band pixels of a patch (<= 2 per thread)
 
 struct PatchArgs {
     AxisC y, x;
-    int PBy, PBx, NS, NB;  // near-band tables of srx_mosaic.hpp (k_build_near)
-    float sn;              // step / N
+    int nn, ntop;               // near-band pixels: all / those of the top rows (the enumeration of k_patch_near_tab)
+    int ngrp;                   // groups of 4 list entries per near-band pixel
+    int c01;                    // the far-field count map is C[gy, gx] = ry[gy] rx[gx], a 0/1 product (full phase grids)
+    unsigned long long ry[4], rx[4];
+    float sn;                   // step / N
+};
+
+// per-call device tables of the patch path
+struct PatchTabs {
+    const float *Mt;            // [B][256 gx][256 gy] far-field LR mosaic, transposed
+    const unsigned *Mt8;        // [B][64][256 gy]: the same as bytes, 4 columns per word (valid where m8[b] != 0)
+    const int *m8;              // [B]: every far-field M of the patch is an integer in [0, 255]
+    const float *Ct;            // [256 gx][256 gy] count map, transposed (unused when c01)
+    const AxisW *aw;            // [2]: y, x
+    const uint2 *nrec;          // [NN_PAD]  x = cnt | cu << 8 | dst << 16, y = strip offset of the pixel's own Y sample
+    const uint2 *nent;          // [ngrp][NN_PAD] four 16-bit strip offsets per group
+    const float2 *Mn;           // [B][NN_PAD] (M, Mu) of the near-band pixels
 };
 
 // ---- eligibility ----------------------------------------------------------------------------------------------------
@@ -100,18 +130,91 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
 // ---- once per call: transposed far-field operands ---------------------------------------------------------------------
 // Mt[b][gx][gy] = M[b][gy + 13][gx + 13] (and Ct from C, plane index B): in row layout a lane is a row, so a wave's load of
 // one column register reads 64 consecutive gy.  grid (8, 8, B + 1), block (32, 8).
+// Also Mt8: the same values as bytes, four columns per word, and m8[b] (preset non-zero by the host) cleared when a value of
+// patch b is not an integer in [0, 255] (uint8 sensor frames with at most one sample per HR pixel: one quarter of the bytes).
 __global__ void __launch_bounds__(256)
-    k_patch_prep(const float *__restrict__ Mg, const float *__restrict__ Cg, int B, int Hg, int Wg, float *__restrict__ Mt, float *__restrict__ Ct)
+    k_patch_prep(const float *__restrict__ Mg, const float *__restrict__ Cg, int B, int Hg, int Wg, int nby, int nbx, float *__restrict__ Mt,
+                 float *__restrict__ Ct, unsigned *__restrict__ Mt8, int *__restrict__ m8)
 {
     __shared__ float t[32][33];
     const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const float *src = b < B ? Mg + (size_t)b * Hg * Wg : Cg;
     float *dst = b < B ? Mt + (size_t)b * PN * PN : Ct;
-    for (int r = threadIdx.y; r < 32; r += 8)
-        t[r][threadIdx.x] = src[(size_t)(y0 + r + 13) * Wg + x0 + threadIdx.x + 13];
+    bool ok = true;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        float v = src[(size_t)(y0 + r + 13) * Wg + x0 + threadIdx.x + 13];
+        if (b < B && (y0 + r < nby || x0 + (int)threadIdx.x < nbx))
+            v = 0.f;  // near band: the kernel takes these pixels from the near-band lists (several frames: sums beyond a byte)
+        ok = ok && v == rintf(v) && v >= 0.f && v <= 255.f;
+        t[r][threadIdx.x] = v;
+    }
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8)
         dst[(size_t)(x0 + r) * PN + y0 + threadIdx.x] = t[threadIdx.x][r];
+    if (b < B) {
+        const int g = threadIdx.y;  // 8 groups of 4 columns
+        const unsigned w = (unsigned)t[threadIdx.x][4 * g] | (unsigned)t[threadIdx.x][4 * g + 1] << 8 |
+                           (unsigned)t[threadIdx.x][4 * g + 2] << 16 | (unsigned)t[threadIdx.x][4 * g + 3] << 24;
+        Mt8[(size_t)b * (PN / 4) * PN + (size_t)(x0 / 4 + g) * PN + y0 + threadIdx.x] = w;
+        if (!ok)
+            atomicAnd(&m8[b], 0);
+    }
+}
+
+// near-band pixel t of the patch enumeration -> natural coordinates and offset in the G strips
+__device__ __forceinline__ void near_coords(int t, int exy, int exx, int nby, int nbx, int &ngy, int &ngx, int &dst)
+{
+    const int WN = PN + exx, LN = exx + nbx, ntop = (exy + nby) * WN;
+    if (t < ntop) {
+        const int rr = t / WN, cc = t - rr * WN;
+        ngy = rr - exy, ngx = cc - exx, dst = rr * YW + cc;
+    } else {
+        const int q = t - ntop, rr = q / LN, cc = q - rr * LN;
+        ngy = nby + rr, ngx = cc - exx, dst = 3 * YW + rr * 3 + cc;
+    }
+}
+// offset of Y[ry, rx] in the strips: top strip rows ry <= nby, left strip otherwise (then rx <= nbx)
+__device__ __forceinline__ int strip_off(int ry, int rx, int exy, int exx, int nby)
+{
+    return ry <= nby ? (ry + exy) * YW + rx + exx : 4 * YW + (ry + exy) * 4 + rx + exx;
+}
+
+// the per-pixel lists of k_build_near, re-expressed for the kernel: strip offsets instead of padded coordinates, grouped so
+// that the threads of a wave read consecutive words.  One thread per near-band pixel.
+__global__ void __launch_bounds__(256)
+    k_patch_near_tab(const int *__restrict__ ncu, const int *__restrict__ nyx, int NS, int PBy, int PBx, int exy, int exx, int nby,
+                     int nbx, int Ey, int Ex, int nn, uint2 *__restrict__ nrec, uint2 *__restrict__ nent)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nn)
+        return;
+    int ngy, ngx, dst;
+    near_coords(t, exy, exx, nby, nbx, ngy, ngx, dst);
+    const int ni = mosaic::near_index(ngy + 13, ngx + 13, PN + 27, PBy, PBx), pk = ncu[ni], cnt = pk & 255, cu = pk >> 8;
+    const int own = strip_off(ngy, ngx, exy, exx, nby);
+    nrec[t] = make_uint2((unsigned)cnt | (unsigned)cu << 8 | (unsigned)dst << 16, (unsigned)own);
+    for (int g = 0; g < NS / 4; g++) {
+        unsigned o[4];
+        for (int e = 0; e < 4; e++) {
+            const int c = nyx[(size_t)ni * NS + 4 * g + e];  // slots past cnt hold an in-range coordinate (k_build_near)
+            o[e] = 4 * g + e < cnt ? (unsigned)strip_off((c & 0xffff) - Ey, (c >> 16) - Ex, exy, exx, nby) : (unsigned)own;
+        }
+        nent[(size_t)g * NN_PAD + t] = make_uint2(o[0] | o[1] << 16, o[2] | o[3] << 16);
+    }
+}
+
+// (M, Mu) of the near-band pixels of every patch.  grid (ceil(nn / 256), B)
+__global__ void __launch_bounds__(256)
+    k_patch_near_m(const float *__restrict__ Mg, const float *__restrict__ Mu, int NB, int PBy, int PBx, int exy, int exx, int nby, int nbx,
+                   int nn, float2 *__restrict__ Mn)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t >= nn)
+        return;
+    int ngy, ngx, dst;
+    near_coords(t, exy, exx, nby, nbx, ngy, ngx, dst);
+    const int Wg = PN + 27, ni = mosaic::near_index(ngy + 13, ngx + 13, Wg, PBy, PBx);
+    Mn[(size_t)b * NN_PAD + t] = make_float2(Mg[((size_t)b * Wg + ngy + 13) * Wg + ngx + 13], Mu[(size_t)b * NB + ni]);
 }
 
 // ---- wave-private 64 x 64 transpose through a 32-row LDS image ----------------------------------------------------------
@@ -142,7 +245,7 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
 // Rown / Rprev / Rnext: LDS regions of this wave and of the waves holding the previous / next block of the line.
 // Two workgroup barriers.  sa: 64-word slot, sb: 192-word slot.
 __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext,
-                                          int sa, int sb, int lane, const AxisC &ax, float &yex)
+                                          int sa, int sb, int lane, const f8 wfb, float &yex)
 {
     const float z = PZ;
     const float bfirst = a[0], blast = a[63];
@@ -174,7 +277,7 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
         cm1 = fmaf(z, a[0], qs);
         cm2 = fmaf(z, cm1, qs);
         const float cm3 = fmaf(z, cm2, qs);
-        yex = ax.wf[0] * cm3 + ax.wf[1] * cm2 + ax.wf[2] * cm1 + ax.wf[3] * a[0];
+        yex = wfb[0] * cm3 + wfb[1] * cm2 + wfb[2] * cm1 + wfb[3] * a[0];
     }
     Rown[sb + lane] = a[0];
     Rown[sb + 64 + lane] = a[62];
@@ -195,7 +298,7 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
 #pragma unroll
     for (int i = 0; i < 64; i++) {
         const float c0 = a[i], cn = i < 63 ? a[i + 1] : hb;
-        a[i] = ax.wf[0] * c2 + ax.wf[1] * c1 + ax.wf[2] * c0 + ax.wf[3] * cn;
+        a[i] = wfb[0] * c2 + wfb[1] * c1 + wfb[2] * c0 + wfb[3] * cn;
         c2 = c1, c1 = c0;
     }
 }
@@ -203,12 +306,13 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
 // ---- backward chain of one block ------------------------------------------------------------------------------------
 // a[] in: G samples of this block; gm1 / gp1 / gp2: G just before / after the block (halo exchange done by the caller);
 // gtop: G[-ex] of the line (first block).  out: corr = blur'( crop P( FIR_b G ) ).  Two workgroup barriers.
+template <typename F>
 __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool first, bool last, float *Rown, const float *Rprev,
-                                          const float *Rnext, int s1, int s6, int lane, const AxisC &ax, float gm1, float gp1,
-                                          float gp2, float gtop)
+                                          const float *Rnext, int s1, int s6, int lane, const f8 wfb, const f8 kt, float gm1, float gp1,
+                                          float gp2, float gtop, F mid)
 {
     const float z = PZ;
-    const float w0 = ax.wb[0], w1 = ax.wb[1], w2 = ax.wb[2], w3 = ax.wb[3];
+    const float w0 = wfb[4], w1 = wfb[5], w2 = wfb[6], w3 = wfb[7];
     const float vn = last ? w0 * a[63] : 0.f;  // v'[n]: the one pad sample below the line whose FIR window holds a real row
     float st = 0.f;
     if (first) {  // the pad: a constant run of G[-ex] (steady state), then the two samples whose window reaches rows 0, 1
@@ -246,6 +350,7 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     Rown[s6 + 256 + lane] = a[62];
     Rown[s6 + 320 + lane] = a[63];
     __syncthreads();
+    mid();        // caller's hook (loads to have in flight during the blur)
     float e[70];  // the block's coefficients with three on either side (zero outside the image)
     e[0] = e[1] = e[2] = e[67] = e[68] = e[69] = 0.f;
     if (!last) {
@@ -265,256 +370,374 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
         e[3 + i] = a[i];
 #pragma unroll
     for (int i = 0; i < 64; i++) {
-        float acc = ax.kt[0] * e[i];
+        float acc = kt[0] * e[i];
 #pragma unroll
         for (int u = 1; u < 7; u++)
-            acc = fmaf(ax.kt[u], e[i + u], acc);
+            acc = fmaf(kt[u], e[i + u], acc);
         out[i] = acc;
     }
 }
 
+// blur (7-tap correlation) of a block with three samples from either neighbour block: halo exchange through the waves' own LDS
+// slots, one workgroup barrier.  a[] in: raw samples, out: sum_k kb[k] x[i - 3 + k] (zero outside the image).
+__device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext,
+                                           int s6, int lane, const f8 kb)
+{
+    Rown[s6 + lane] = a[0];
+    Rown[s6 + 64 + lane] = a[1];
+    Rown[s6 + 128 + lane] = a[2];
+    Rown[s6 + 192 + lane] = a[61];
+    Rown[s6 + 256 + lane] = a[62];
+    Rown[s6 + 320 + lane] = a[63];
+    __syncthreads();
+    float x[70];
+    x[0] = x[1] = x[2] = x[67] = x[68] = x[69] = 0.f;
+    if (!first)
+        x[0] = Rprev[s6 + 192 + lane], x[1] = Rprev[s6 + 256 + lane], x[2] = Rprev[s6 + 320 + lane];
+    if (!last)
+        x[67] = Rnext[s6 + lane], x[68] = Rnext[s6 + 64 + lane], x[69] = Rnext[s6 + 128 + lane];
+#pragma unroll
+    for (int j = 0; j < 64; j++)
+        x[3 + j] = a[j];
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        float acc = kb[0] * x[j];
+#pragma unroll
+        for (int k = 1; k < 7; k++)
+            acc = fmaf(kb[k], x[j + k], acc);
+        a[j] = acc;
+    }
+}
+
 // =========================================================================================================================
-// One IBP iteration of one patch.  grid B, block 1024.
+// All n_iter IBP iterations of one patch.  grid B, block 1024 (16 waves = 4 x 4 blocks of 64 x 64).
+// Between iterations the HR state stays in registers (column layout); per iteration the kernel stores it (hr_out doubles as
+// the parking place of the pre-update state, re-read for the update -- the register file holds the state OR the working
+// plane, not both), reads the LR mosaic (bytes when the patch's samples are uint8) and the near-band descriptors.
 // =========================================================================================================================
+struct AxisWPair {
+    AxisW y, x;
+};
+__global__ void k_patch_params(AxisWPair v, AxisW *dst)
+{
+    dst[0] = v.y;
+    dst[1] = v.x;
+}
+
+template <bool C01>
 __global__ void __launch_bounds__(1024)
-    k_ibp_patch(const float *__restrict__ hr_in, float *__restrict__ hr_out, const float *__restrict__ Mt, const float *__restrict__ Ct,
-                const float *__restrict__ Mg, const float *__restrict__ Mu, const int *__restrict__ ncu, const int *__restrict__ nyx,
-                PatchArgs pa, const double *__restrict__ Vtot, double scale, double *__restrict__ errors, int errors_stride)
+    k_ibp_patch(const float *__restrict__ hr_in, float *__restrict__ hr_out, PatchTabs tb, PatchArgs pa, const double *__restrict__ Vtot,
+                double scale, double *__restrict__ errors, int n_iter)
 {
     __shared__ float lds[LDS_WORDS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave >> 2, u = wave & 3;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), s = wave >> 2, u = wave & 3;
     const int b = blockIdx.x;
     float *Rown = lds + wave * RW;
     const float *Rup = lds + (wave - 4) * RW, *Rdn = lds + (wave + 4) * RW;  // vertical neighbours (same u)
     const float *Rlf = lds + (wave - 1) * RW, *Rrt = lds + (wave + 1) * RW;  // horizontal neighbours (same s)
-    float *Yt = lds + OFF_YT, *Yl = lds + OFF_YL, *Gt = lds + OFF_GT, *Gl = lds + OFF_GL, *rowbuf = lds + OFF_ROW;
+    float *Ystrip = lds + OFF_YT, *Gstrip = lds + OFF_GT, *rowbuf = lds + OFF_ROW;
+    float *Yt = lds + OFF_YT, *Yl = lds + OFF_YL, *Gt = lds + OFF_GT, *Gl = lds + OFF_GL;
     double *part = reinterpret_cast<double *>(lds + OFF_PART);
     const int exy = pa.y.ex, exx = pa.x.ex, nby = pa.y.nb, nbx = pa.x.nb;
-    const int Wg = PN + 27;
 
     const __amdgpu_buffer_rsrc_t rs_in = fused::plane_rsrc(hr_in + (size_t)b * PN * PN, (size_t)PN * PN);
     const __amdgpu_buffer_rsrc_t rs_out = fused::plane_rsrc(hr_out + (size_t)b * PN * PN, (size_t)PN * PN);
-    const int l4 = lane * 4;
+    const int m8 = __builtin_amdgcn_readfirstlane(tb.m8[b]);
+    const float *awy = tb.aw[0].kb, *awx = tb.aw[1].kb;  // 24 floats each: kb | kt | wfb
+    const int nn = pa.nn;
+    const float sn = pa.sn;
+    const int cb0 = (64 * s * PN + 64 * u) * 4;  // byte offset of this wave's block in column layout (row pitch PN)
+    const int tb0 = (64 * u * PN + 64 * s) * 4;  // ... in the transposed planes (Mt, Ct): register = column, lane = row
+    // 0/1 count map of a full phase grid: this wave's 64 row bits (row layout: bit = lane) and 64 column bits
+    const unsigned long long rmask = C01 ? pa.ry[s] : 0ull, cmask = C01 ? pa.rx[u] : 0ull;
 
-    float a[64], r[64];
-    // ================= stage A: column layout, lane = column 64 u + lane, a[i] = row 64 s + i =================
-    {
-        float xin[70];
+    // The state lives in hr_out between iterations: every iteration reads its block at the top (an L2 hit: this wave wrote it)
+    // and writes the updated block at the bottom.  Carrying the 64 registers across the loop edge instead made the register
+    // allocator spill ~180 values per iteration; the copy in hr_out is needed anyway (the pre-update state for the update).
+    if (hr_in != hr_out) {
+        const int l4 = (tid0 & 63) * 4;
 #pragma unroll
-        for (int i = 0; i < 70; i++) {
-            const int row = 64 * s + i - 3;  // wave-uniform
-            xin[i] = (row >= 0 && row < PN) ? fused::buf_load<float>(rs_in, l4, (row * PN + 64 * u) * 4) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            float acc = pa.y.kb[0] * xin[i];
-#pragma unroll
-            for (int k = 1; k < 7; k++)
-                acc = fmaf(pa.y.kb[k], xin[i + k], acc);
-            a[i] = acc;
-        }
-    }
-    float yex = 0.f;
-    fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, SLOT1, lane, pa.y, yex);
-    if (exy) {  // the Y row above the grid rides in the grid's last row (empty: axis_ok)
-        if (s == 0)
-            rowbuf[64 * u + lane] = yex;
-    }
-    __syncthreads();  // also: every wave is done with the exchange slots before the transposes overwrite them
-    if (exy && s == 3)
-        a[63] = rowbuf[64 * u + lane];
-    transpose64(a, r, Rown, lane);
-    // ================= stage B: row layout, lane = row 64 s + lane, r[j] = column 64 u + j =================
-    const bool wrapped = exy && s == 3 && lane == 63;    // this lane holds row -1
-    const int gy = wrapped ? -1 : 64 * s + lane;          // natural row of this lane
-    {
-        // blur along x: three raw samples from either neighbour
-        Rown[SLOT0 + lane] = r[0];
-        Rown[SLOT0 + 64 + lane] = r[1];
-        Rown[SLOT0 + 128 + lane] = r[2];
-        Rown[SLOT0 + 192 + lane] = r[61];
-        Rown[SLOT0 + 256 + lane] = r[62];
-        Rown[SLOT0 + 320 + lane] = r[63];
-        __syncthreads();
-        float xin[70];
-        xin[0] = xin[1] = xin[2] = xin[67] = xin[68] = xin[69] = 0.f;
-        if (u > 0)
-            xin[0] = Rlf[SLOT0 + 192 + lane], xin[1] = Rlf[SLOT0 + 256 + lane], xin[2] = Rlf[SLOT0 + 320 + lane];
-        if (u < 3)
-            xin[67] = Rrt[SLOT0 + lane], xin[68] = Rrt[SLOT0 + 64 + lane], xin[69] = Rrt[SLOT0 + 128 + lane];
-#pragma unroll
-        for (int j = 0; j < 64; j++)
-            xin[3 + j] = r[j];
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-            float acc = pa.x.kb[0] * xin[j];
-#pragma unroll
-            for (int k = 1; k < 7; k++)
-                acc = fmaf(pa.x.kb[k], xin[j + k], acc);
-            a[j] = acc;
-        }
-    }
-    float yexx = 0.f;  // Y[gy, -1] (u == 0)
-    fwd_chain(a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT1, SLOT0, lane, pa.x, yexx);
-    // ---- near-band strips of Y
-    {
-        const bool toprow = wrapped || (s == 0 && lane <= nby);
-        if (toprow) {
-            float *dst = Yt + (gy + exy) * YW + 64 * u + exx;
-#pragma unroll
-            for (int j = 0; j < 64; j++)
-                dst[j] = a[j];
-            if (u == 0 && exx)
-                dst[-1] = yexx;
-        }
-        if (u == 0) {
-            float *dst = Yl + (gy + exy) * 4 + exx;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                if (j <= nbx)
-                    dst[j] = a[j];
-            if (exx)
-                dst[-1] = yexx;
-        }
-    }
-    __syncthreads();
-    // ---- near band: G = M - sum of the listed Y samples; the counted samples' share of the MSE trace
-    float sq = 0.f;
-    {
-        const int WN = PN + exx, LN = exx + nbx, ntop = (exy + nby) * WN, nn = ntop + (PN - nby) * LN;
-        const float *Mgb = Mg + (size_t)b * (PN + 27) * Wg, *Mub = Mu + (size_t)b * pa.NB;
-        for (int t = tid; t < nn; t += 1024) {
-            int ngy, ngx;
-            float *dst;
-            if (t < ntop) {
-                const int rr = t / WN, cc = t - rr * WN;
-                ngy = rr - exy, ngx = cc - exx;
-                dst = Gt + rr * YW + cc;
-            } else {
-                const int q = t - ntop, rr = q / LN, cc = q - rr * LN;
-                ngy = nby + rr, ngx = cc - exx;
-                dst = Gl + rr * 3 + cc;
-            }
-            const int pp = ngy + 13, qq = ngx + 13;
-            const int ni = mosaic::near_index(pp, qq, Wg, pa.PBy, pa.PBx), pk = ncu[ni], cnt = pk & 255, cu = pk >> 8;
-            auto Yat = [&](int ry, int rx) -> float {  // natural coordinates; ry <= nby -> top strip, else left strip
-                return ry <= nby ? Yt[(ry + exy) * YW + rx + exx] : Yl[(ry + exy) * 4 + rx + exx];
-            };
-            float ys = 0.f;
-            for (int e = 0; e < cnt; e++) {
-                const int c = nyx[(size_t)ni * pa.NS + e];
-                ys += Yat((c & 0xffff) - pa.y.E, (c >> 16) - pa.x.E);
-            }
-            *dst = Mgb[(size_t)pp * Wg + qq] - ys;
-            if (cu > 0) {
-                const float gu = Mub[ni] - (float)cu * Yat(ngy, ngx);
-                sq += gu * gu / (float)cu;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- G = M - C Y on the grid; near-band pixels take their value from the strips
-    float gexx = 0.f;  // G[gy, -1]
-    {
-        const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(Mt + (size_t)b * PN * PN, (size_t)PN * PN);
-        const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(Ct, (size_t)PN * PN);
-        const bool rownear = wrapped || gy < nby;
-        float sqf = 0.f;
-#pragma unroll
-        for (int j0 = 0; j0 < 64; j0 += 16) {
-            float mv[16], cv[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int so = ((64 * u + j0 + j) * PN + 64 * s) * 4;
-                mv[j] = fused::buf_load<float>(rsM, l4, so);
-                cv[j] = fused::buf_load<float>(rsC, l4, so);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float g = fmaf(-cv[j], a[j0 + j], mv[j]);
-                const bool far = !rownear && 64 * u + j0 + j >= nbx;
-                sqf += far ? g * g * mosaic::rcp_count(cv[j]) : 0.f;
-                a[j0 + j] = g;
-            }
-        }
-        sq += sqf;
-        if (rownear) {
-            const float *src = Gt + (gy + exy) * YW + 64 * u + exx;
-#pragma unroll
-            for (int j = 0; j < 64; j++)
-                a[j] = src[j];
-            if (u == 0 && exx)
-                gexx = src[-1];
-        } else if (u == 0) {
-            const float *src = Gl + (gy - nby) * 3 + exx;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                if (j < nbx)
-                    a[j] = src[j];
-            if (exx)
-                gexx = src[-1];
-        }
-    }
-    // ---- H-bwd
-    {
-        Rown[SLOT1 + lane] = a[0];
-        Rown[SLOT1 + 64 + lane] = a[1];
-        Rown[SLOT1 + 128 + lane] = a[63];
-        __syncthreads();
-        const float gtop = exx ? gexx : a[0];
-        const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];
-        const float gp1 = u == 3 ? 0.f : Rrt[SLOT1 + lane], gp2 = u == 3 ? 0.f : Rrt[SLOT1 + 64 + lane];
-        bwd_chain(a, r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, pa.x, gm1, gp1, gp2, gtop);
-    }
-    __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
-    transpose64(r, a, Rown, lane);
-    // ================= stage C: column layout again, a[i] = row 64 s + i (row 63 of s == 3: the wrapped row -1) =================
-    {
-        if (exy && s == 3) {
-            rowbuf[64 * u + lane] = a[63];
-            a[63] = 0.f;
-        }
-        Rown[SLOT0 + lane] = a[0];
-        Rown[SLOT0 + 64 + lane] = a[1];
-        Rown[SLOT0 + 128 + lane] = a[63];
-        __syncthreads();
-        const float gtop = exy ? rowbuf[64 * u + lane] : a[0];
-        const float gm1 = s == 0 ? gtop : Rup[SLOT0 + 128 + lane];
-        const float gp1 = s == 3 ? 0.f : Rdn[SLOT0 + lane], gp2 = s == 3 ? 0.f : Rdn[SLOT0 + 64 + lane];
-        bwd_chain(a, r, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, pa.y, gm1, gp1, gp2, gtop);
-    }
-    // ---- update
-#pragma unroll
-    for (int i0 = 0; i0 < 64; i0 += 16) {
-        float hv[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            hv[i] = fused::buf_load<float>(rs_in, l4, ((64 * s + i0 + i) * PN + 64 * u) * 4);
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float v = fmaf(r[i0 + i], pa.sn, hv[i]);
-            fused::buf_store<float>(v < 0.f ? 0.f : (v > 255.f ? 255.f : v), rs_out, l4, ((64 * s + i0 + i) * PN + 64 * u) * 4);
-        }
-    }
-    // ---- MSE trace of this iteration (before the update): fixed summation order
-    if (errors) {
-        const double ws = wave_sum((double)sq);
-        if (lane == 0)
-            part[wave] = ws;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
+        for (int i0 = 0; i0 < 64; i0 += 16) {
+            float t[16];
 #pragma unroll
             for (int i = 0; i < 16; i++)
-                t += part[i];
-            errors[(size_t)b * errors_stride] = (t + Vtot[b]) * scale;
+                t[i] = fused::buf_load<float>(rs_in, l4 + (i & 3) * PN * 4, cb0 + ((i0 + i) >> 2) * PN * 16);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                fused::buf_store<float>(t[i], rs_out, l4 + (i & 3) * PN * 4, cb0 + ((i0 + i) >> 2) * PN * 16);
+        }
+    }
+
+    for (int it = 0; it < n_iter; it++) {
+        float a[64], r[64];
+        // everything derived from the lane index is re-derived per iteration from an opaque copy: hoisted out of the loop, the
+        // ~45 lane-dependent addresses and predicates do not fit beside the working plane and were spilled, one scratch
+        // round trip per use
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, l4 = lane * 4;
+        const bool wrapped = exy && s == 3 && lane == 63;  // row layout: this lane holds row -1
+        const int gy = wrapped ? -1 : 64 * s + lane;       // row layout: natural row of this lane
+        const bool rownear = wrapped || gy < nby;
+        const float crow = C01 ? (float)((rmask >> lane) & 1ull) : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(0);
+        // opaque copies of the block offsets: otherwise every row / column offset derived from them is hoisted out of this
+        // loop and kept (and spilled) in scalar registers
+        int cbl = cb0, tbl = tb0, m8l = (16 * u * PN + 64 * s) * 4;
+        asm volatile("" : "+s"(cbl), "+s"(tbl), "+s"(m8l));
+        // ================= stage A: column layout, lane = column 64 u + lane, a[i] = row 64 s + i =================
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            a[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
+        blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(1);
+        float yex = 0.f;
+        fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1, SLOT0, lane, sload8(awy + 16), yex);
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(2);
+        if (exy && s == 0)  // the Y row above the grid rides in the grid's last row (empty: axis_ok)
+            rowbuf[64 * u + lane] = yex;
+        __syncthreads();  // also: every wave is done with the exchange slots before the transposes overwrite them
+        if (exy && s == 3)
+            a[63] = rowbuf[64 * u + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(3);
+        transpose64(a, r, Rown, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(4);
+        // ================= stage B: row layout, lane = row 64 s + lane, r[j] = column 64 u + j =================
+        blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
+        __builtin_amdgcn_sched_barrier(0);
+        // operands of the G step and of the near band, in flight during the H-fwd chain (issued after the blur: its 70-register window is this stage's peak)
+        const __amdgpu_buffer_rsrc_t rsM8 = fused::plane_rsrc(tb.Mt8 + (size_t)b * (PN / 4) * PN, (size_t)(PN / 4) * PN);
+        unsigned m8w[16];
+        if (m8) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                m8w[k] = __builtin_amdgcn_raw_buffer_load_b32(rsM8, l4 + (k & 3) * PN * 4, m8l + (k >> 2) * PN * 16, 0);
+        }
+        uint2 nr0 = make_uint2(0, 0), nr1 = make_uint2(0, 0), ne0 = make_uint2(0, 0), ne1 = make_uint2(0, 0);
+        float2 nm0 = make_float2(0.f, 0.f), nm1 = make_float2(0.f, 0.f);
+        const bool n0 = tid < nn, n1 = tid + 1024 < nn;
+        if (n0)
+            nr0 = tb.nrec[tid], ne0 = tb.nent[tid], nm0 = tb.Mn[(size_t)b * NN_PAD + tid];
+        if (n1)
+            nr1 = tb.nrec[tid + 1024], ne1 = tb.nent[tid + 1024], nm1 = tb.Mn[(size_t)b * NN_PAD + tid + 1024];
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(5);
+        float yexx = 0.f;  // Y[gy, -1] (u == 0)
+        fwd_chain(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT1, SLOT0, lane, sload8(awx + 16), yexx);
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(6);
+        // ---- near-band strips of Y
+        {
+            const bool toprow = wrapped || (s == 0 && lane <= nby);
+            if (toprow) {
+                float *dst = Yt + (gy + exy) * YW + 64 * u + exx;
+#pragma unroll
+                for (int j = 0; j < 64; j++)
+                    dst[j] = r[j];
+                if (u == 0 && exx)
+                    dst[-1] = yexx;
+            }
+            if (u == 0) {
+                float *dst = Yl + (gy + exy) * 4 + exx;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (j <= nbx)
+                        dst[j] = r[j];
+                if (exx)
+                    dst[-1] = yexx;
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(7);
+        // ---- near band: G = M - sum of the listed Y samples; the counted samples' share of the MSE trace
+        float sq = 0.f;
+        {
+            auto near_px = [&](uint2 nr, uint2 ne, float2 nm, int t) {
+                const int cnt = nr.x & 255, cu = (nr.x >> 8) & 255, dst = nr.x >> 16;
+                float ys = (cnt > 0 ? Ystrip[ne.x & 0xffff] : 0.f) + (cnt > 1 ? Ystrip[ne.x >> 16] : 0.f) +
+                           (cnt > 2 ? Ystrip[ne.y & 0xffff] : 0.f) + (cnt > 3 ? Ystrip[ne.y >> 16] : 0.f);
+                for (int g = 1; 4 * g < cnt; g++) {  // more than 4 frames on a pixel: the corner, or frames sharing a phase
+                    const uint2 e = tb.nent[(size_t)g * NN_PAD + t];
+                    const int c = cnt - 4 * g;
+                    ys += (c > 0 ? Ystrip[e.x & 0xffff] : 0.f) + (c > 1 ? Ystrip[e.x >> 16] : 0.f) + (c > 2 ? Ystrip[e.y & 0xffff] : 0.f) +
+                          (c > 3 ? Ystrip[e.y >> 16] : 0.f);
+                }
+                Gstrip[dst] = nm.x - ys;
+                if (cu > 0) {
+                    const float gu = nm.y - (float)cu * Ystrip[nr.y];
+                    sq += (SRX_PATCH_DBG & 64) ? 0.f : gu * gu / (float)cu;
+                }
+            };
+            if (n0 && !(SRX_PATCH_DBG & 4))
+                near_px(nr0, ne0, nm0, tid);
+            if (n1 && !(SRX_PATCH_DBG & 4))
+                near_px(nr1, ne1, nm1, tid + 1024);
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(8);
+        // ---- G = M - C Y on the grid; near-band pixels take their value from the strips
+        float gexx = 0.f;  // G[gy, -1]
+        {
+            const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(tb.Mt + (size_t)b * PN * PN, (size_t)PN * PN);
+            const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(tb.Ct, (size_t)PN * PN);
+            float sqf = 0.f;
+            // the per-column predicates below are wave-uniform and loop-invariant: from an opaque copy of the mask, or all 64 of
+            // them are hoisted out of the iteration loop as 64-bit lane masks (256 scalar registers, spilled)
+            unsigned long long cm = cmask;
+            asm volatile("" : "+s"(cm));
+            float gn[3] = {0.f, 0.f, 0.f};  // squares of the first three columns: near band when u == 0 (subtracted again below)
+            if (m8) {
+#pragma unroll
+                for (int j = 0; j < 64; j++) {
+                    const float mv = (float)((m8w[j >> 2] >> (8 * (j & 3))) & 255u);
+                    float g, w;
+                    if (C01) {
+                        const bool on = (cm >> j) & 1ull;  // wave-uniform; M = 0 where no frame contributes
+                        g = on ? fmaf(-crow, r[j], mv) : 0.f;
+                        w = 1.f;
+                    } else {
+                        const float cv = fused::buf_load<float>(rsC, l4 + (j & 3) * PN * 4, tbl + (j >> 2) * PN * 16);
+                        g = fmaf(-cv, r[j], mv);
+                        w = mosaic::rcp_count(cv);
+                    }
+                    const float g2 = g * g * w;
+                    sqf += g2;
+                    if (j < 3)
+                        gn[j] = g2;
+                    r[j] = g;
+                }
+            } else {
+#pragma unroll
+                for (int j0 = 0; j0 < 64; j0 += 16) {
+                    float mv[16], cv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        mv[j] = fused::buf_load<float>(rsM, l4 + (j & 3) * PN * 4, tbl + ((j0 + j) >> 2) * PN * 16);
+                        cv[j] = C01 ? (((cm >> (j0 + j)) & 1ull) ? crow : 0.f)
+                                    : fused::buf_load<float>(rsC, l4 + (j & 3) * PN * 4, tbl + ((j0 + j) >> 2) * PN * 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const float g = fmaf(-cv[j], r[j0 + j], mv[j]);
+                        const float g2 = g * g * (C01 ? 1.f : mosaic::rcp_count(cv[j]));
+                        sqf += g2;
+                        if (j0 + j < 3)
+                            gn[j0 + j] = g2;
+                        r[j0 + j] = g;
+                    }
+                }
+            }
+            if (u == 0)  // the first nbx columns of the grid are near band: not part of the far-field sum
+                sqf -= (nbx > 0 ? gn[0] : 0.f) + (nbx > 1 ? gn[1] : 0.f) + (nbx > 2 ? gn[2] : 0.f);
+            sq += (rownear || (SRX_PATCH_DBG & 32)) ? 0.f : sqf;
+            if (rownear) {
+                const float *src = Gt + (gy + exy) * YW + 64 * u + exx;
+#pragma unroll
+                for (int j = 0; j < 64; j++)
+                    r[j] = src[j];
+                if (u == 0 && exx)
+                    gexx = src[-1];
+            } else if (u == 0) {
+                const float *src = Gl + (gy - nby) * 3 + exx;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (j < nbx)
+                        r[j] = src[j];
+                if (exx)
+                    gexx = src[-1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(9);
+        // ---- H-bwd
+        {
+            Rown[SLOT1 + lane] = r[0];
+            Rown[SLOT1 + 64 + lane] = r[1];
+            Rown[SLOT1 + 128 + lane] = r[63];
+            __syncthreads();
+            const float gtop = exx ? gexx : r[0];
+            const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];
+            const float gp1 = u == 3 ? 0.f : Rrt[SLOT1 + lane], gp2 = u == 3 ? 0.f : Rrt[SLOT1 + 64 + lane];
+            bwd_chain(r, a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop, [] {});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(10);
+        __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(11);
+        transpose64(a, r, Rown, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(12);
+        // ================= stage C: column layout again, r[i] = row 64 s + i (row 63 of s == 3: the wrapped row -1) =================
+        float hv[16], hw[16];  // the parked state, 16 rows at a time; the first batch is in flight during the last blur
+        {
+            if (exy && s == 3) {
+                rowbuf[64 * u + lane] = r[63];
+                r[63] = 0.f;
+            }
+            Rown[SLOT0 + lane] = r[0];
+            Rown[SLOT0 + 64 + lane] = r[1];
+            Rown[SLOT0 + 128 + lane] = r[63];
+            __syncthreads();
+            const float gtop = exy ? rowbuf[64 * u + lane] : r[0];
+            const float gm1 = s == 0 ? gtop : Rup[SLOT0 + 128 + lane];
+            const float gp1 = s == 3 ? 0.f : Rdn[SLOT0 + lane], gp2 = s == 3 ? 0.f : Rdn[SLOT0 + 64 + lane];
+            bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, [&] {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    hv[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(13);
+        // ---- update: the new state
+        {
+            // clip(hr + step * corr / N, 0, 255) as one v_med3_f32 (compare + select pairs made the compiler keep 64 lane masks)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float(&cur)[16] = (q & 1) ? hw : hv;
+                float(&nxt)[16] = (q & 1) ? hv : hw;
+                if (q < 3) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        nxt[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (4 * (q + 1) + (i >> 2)) * PN * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    fused::buf_store<float>(__builtin_amdgcn_fmed3f(fmaf(a[16 * q + i], sn, cur[i]), 0.f, 255.f), rs_out, l4 + (i & 3) * PN * 4,
+                                            cbl + (4 * q + (i >> 2)) * PN * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(14);
+        // ---- MSE trace of this iteration (before the update): fixed summation order
+        if (errors) {
+            const double ws = wave_sum((double)sq);
+            if (lane == 0)
+                part[wave] = ws;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    t += part[i];
+                errors[(size_t)b * n_iter + it] = (t + Vtot[b]) * scale;
+            }
         }
     }
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
-static inline void fill_axis(const mosaic::AxisPlan &pl, int N, const float *cfwd, const float *cbwd, AxisC &ax)
+static inline void fill_axis(const mosaic::AxisPlan &pl, int N, const float *cfwd, const float *cbwd, AxisC &ax, AxisW &aw)
 {
     const double kq = -6.0 * ZD;
     int nmin = pl.n[0], nmax = pl.n[0];
@@ -523,34 +746,117 @@ static inline void fill_axis(const mosaic::AxisPlan &pl, int N, const float *cfw
     double wv[4];
     fused::host_weights(1.0 - pl.delta, wv);
     for (int i = 0; i < 4; i++)
-        ax.wf[i] = (float)wv[i];
+        aw.wfb[i] = (float)wv[i];
     fused::host_weights(pl.delta, wv);
     for (int i = 0; i < 4; i++)
-        ax.wb[i] = (float)(kq * wv[i]);
+        aw.wfb[4 + i] = (float)(kq * wv[i]);
+    aw.kb[7] = aw.kt[7] = 0.f;
     for (int i = 0; i < 7; i++)
-        ax.kb[i] = (float)(kq * (double)cfwd[i]), ax.kt[i] = cbwd[i];
+        aw.kb[i] = (float)(kq * (double)cfwd[i]), aw.kt[i] = cbwd[i];
     ax.ex = nmax, ax.nb = -nmin, ax.E = pl.E;
 }
 
-// the iteration loop; the per-call tables (M, C, Mu, near lists, Vtot) are srx_mosaic.hpp's, built by its ibp()
-static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
-                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
-                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, float *Mt, float *Ct, int n_iter, double step,
-                   double scale, double *errors, hipStream_t st)
+// Full phase grids (every frame its own (row class, column class), classes distinct modulo f): each far-field HR pixel
+// holds at most one sample and the count map is the product of a row mask and a column mask.
+static inline bool c01_masks(const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, int N, int f, unsigned long long ry[4],
+                             unsigned long long rx[4])
 {
-    const int Hg = PN + 27, Wg = PN + 27;
-    PatchArgs pa;
-    fill_axis(py, N, kc.cy, kt.cy, pa.y);
-    fill_axis(px, N, kc.cx, kt.cx, pa.x);
-    pa.PBy = py.PB, pa.PBx = px.PB, pa.NS = NS, pa.NB = NB;
-    pa.sn = (float)step / (float)N;
-    hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, Mt, Ct);
-    SRX_CHECK_LAUNCH();
-    for (int it = 0; it < n_iter; it++) {
-        const float *cur = it == 0 ? hr_init : hr;
-        SRX_LAUNCH(KID_IBP_PATCH, k_ibp_patch, dim3(B), dim3(1024), 0, st, cur, hr, Mt, Ct, Mg, Mu, ncu, nyx, pa, Vtot, scale,
-                   errors ? errors + it : nullptr, n_iter);
+    int ny[SRX_MAX_FRAMES], nx[SRX_MAX_FRAMES], cy = 0, cx = 0;
+    for (int k = 0; k < N; k++) {
+        bool fy = false, fx = false;
+        for (int j = 0; j < cy; j++)
+            fy = fy || ny[j] == py.n[k];
+        for (int j = 0; j < cx; j++)
+            fx = fx || nx[j] == px.n[k];
+        if (!fy)
+            ny[cy++] = py.n[k];
+        if (!fx)
+            nx[cx++] = px.n[k];
+        for (int j = 0; j < k; j++)
+            if (py.n[j] == py.n[k] && px.n[j] == px.n[k])
+                return false;  // two frames on one phase
     }
+    if (cy * cx != N)
+        return false;
+    for (int i = 0; i < cy; i++)
+        for (int j = 0; j < i; j++)
+            if ((ny[i] - ny[j]) % f == 0)
+                return false;
+    for (int i = 0; i < cx; i++)
+        for (int j = 0; j < i; j++)
+            if ((nx[i] - nx[j]) % f == 0)
+                return false;
+    for (int w = 0; w < 4; w++)
+        ry[w] = rx[w] = 0ull;
+    for (int g = 0; g < PN; g++) {
+        for (int i = 0; i < cy; i++) {
+            const int uu = g + ny[i];
+            if (uu >= 0 && uu <= PN - 1 && uu % f == 0)
+                ry[g >> 6] |= 1ull << (g & 63);
+        }
+        for (int i = 0; i < cx; i++) {
+            const int uu = g + nx[i];
+            if (uu >= 0 && uu <= PN - 1 && uu % f == 0)
+                rx[g >> 6] |= 1ull << (g & 63);
+        }
+    }
+    return true;
+}
+
+// device memory of the patch path's tables, carved from the caller's workspace by mosaic::ibp
+static inline size_t tabs_bytes(int B, int N)
+{
+    const size_t ngrp = ((size_t)N + 3) / 4;
+    return align_up((size_t)B * PN * PN * 4) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * 4) +
+           align_up((size_t)NN_PAD * 8) + align_up(ngrp * NN_PAD * 8) + align_up((size_t)B * NN_PAD * 8) + align_up(2 * sizeof(AxisW));
+}
+
+// the iteration loop; the per-call tables (M, C, Mu, near lists, Vtot) are srx_mosaic.hpp's, built by its ibp()
+static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int n_iter, double step, double scale,
+                   double *errors, hipStream_t st)
+{
+    const int Hg = PN + 27, Wg = PN + 27, ngrp = NS / 4;
+    float *Mt = ar.take<float>((size_t)B * PN * PN);
+    unsigned *Mt8 = ar.take<unsigned>((size_t)B * (PN / 4) * PN);
+    int *m8 = ar.take<int>(B);
+    float *Ct = ar.take<float>((size_t)PN * PN);
+    uint2 *nrec = ar.take<uint2>(NN_PAD), *nent = ar.take<uint2>((size_t)ngrp * NN_PAD);
+    float2 *Mn = ar.take<float2>((size_t)B * NN_PAD);
+    AxisW *aw = ar.take<AxisW>(2);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    PatchArgs pa;
+    AxisWPair awp;
+    fill_axis(py, N, kc.cy, kt.cy, pa.y, awp.y);
+    fill_axis(px, N, kc.cx, kt.cx, pa.x, awp.x);
+    pa.sn = (float)step / (float)N;
+    pa.ntop = (pa.y.ex + pa.y.nb) * (PN + pa.x.ex);
+    pa.nn = pa.ntop + (PN - pa.y.nb) * (pa.x.ex + pa.x.nb);
+    pa.ngrp = ngrp;
+    if (pa.nn > NN_PAD)
+        return SRX_E_UNSUPPORTED;
+    pa.c01 = c01_masks(py, px, N, f, pa.ry, pa.rx) ? 1 : 0;
+    if (hipMemsetAsync(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+        return SRX_E_HIP;
+    hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
+    SRX_CHECK_LAUNCH();
+    if (pa.nn > 0) {
+        hipLaunchKernelGGL(k_patch_near_tab, dim3(cdiv(pa.nn, 256)), dim3(256), 0, st, ncu, nyx, NS, py.PB, px.PB, pa.y.ex, pa.x.ex, pa.y.nb,
+                           pa.x.nb, pa.y.E, pa.x.E, pa.nn, nrec, nent);
+        SRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_patch_near_m, dim3(cdiv(pa.nn, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, pa.y.ex, pa.x.ex, pa.y.nb,
+                           pa.x.nb, pa.nn, Mn);
+        SRX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
+    SRX_CHECK_LAUNCH();
+    PatchTabs tb{Mt, Mt8, m8, Ct, aw, nrec, nent, Mn};
+    if (pa.c01)
+        SRX_LAUNCH(KID_IBP_PATCH, k_ibp_patch<true>, dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+    else
+        SRX_LAUNCH(KID_IBP_PATCH, k_ibp_patch<false>, dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
     return SRX_OK;
 }
 

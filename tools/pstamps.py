@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase stamps of k_ibp_patch from a DIAGNOSTIC build (hipcc -DSRX_STAMPS -> libsrx_stamps.so): s_memtime by lane 0 of every
+wave at phase boundaries.  Shares only; the stamps themselves cost cycles.
+    SRX_LIB=.../libsrx_stamps.so python tools/pstamps.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enph459-super-resolution_amd"))
+import torch  # noqa: E402
+import sr_mi355x as S  # noqa: E402
+from sr_mi355x import _lib, synth  # noqa: E402
+
+f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), int(os.environ.get("STAMPS_B", "1024"))
+lr = torch.round(torch.rand((B, 16, 64, 64), device="cuda") * 255)
+saa = S.shift_and_add_batched(lr, shifts, f)
+S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
+NPH = 15
+buf = np.zeros((24, 4096), dtype=np.uint64)
+lib = _lib.load()
+lib.srx_debug_pstamps.argtypes = [ctypes.c_void_p]
+assert lib.srx_debug_pstamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+nb = min(B, 256)
+t = buf[:NPH].astype(np.int64).reshape(NPH, 256, 16)[:, :nb]
+names = ["park state + blur_v (1 barrier)", "V-fwd chain (2 barriers)", "rowbuf + barrier", "transpose 1", "prefetch + blur_h (1 barrier)",
+         "H-fwd chain (2 barriers)", "strips + barrier", "near band + barrier", "G = M - C Y", "H-bwd (3 barriers)", "barrier",
+         "transpose 2", "V-bwd (3 barriers)", "update"]
+tot = t[NPH - 1] - t[0]
+print(f"k_ibp_patch, last iteration: {nb} blocks x 16 waves; cycles per wave, first -> last stamp: median {np.median(tot):.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f}")
+for i in range(NPH - 1):
+    d = t[i + 1] - t[i]
+    print(f"  {names[i]:34s} median {np.median(d):8.0f}   mean {d.mean():8.0f}   min {d.min():7d}  max {d.max():7d}   share {100 * d.mean() / tot.mean():5.1f} %")
