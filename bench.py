@@ -51,7 +51,7 @@ def make_inputs(S, synth, B, f, lr_hw, shifts, psf, n_unique, prec, seed_base):
     return lr.contiguous(), truths
 
 
-def kernel_model_bytes(name, B, N, h, w, f, eb):
+def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
     """Algorithmic (minimum) HBM bytes of ONE launch of a fused-path kernel at these shapes."""
     H, W = h * f, w * f
     hw, pad, lrn = B * H * W * eb, B * (H + 24) * (W + 24) * eb, B * N * h * w * eb
@@ -64,9 +64,91 @@ def kernel_model_bytes(name, B, N, h, w, f, eb):
         "k_blurT_update": pad + 2 * hw,         # read padded coefficients + hr, write hr
         "k_fwd_tile": pad + 2 * lrn,            # read padded blur + LR frames, write residuals
         "k_bwd_tile": lrn + 2 * hw,             # read residuals + hr, write hr
-        "k_fwd_mosaic": hw + 2 * B * (H + 27) * (W + 27) * eb,   # read blurred plane + LR mosaic, write G
+        "k_fwd_mosaic": hw + 2 * B * (H + 27) * (W + 27) * eb,   # read blurred plane (or hr) + LR mosaic, write G
         "k_bwd_mosaic": B * (H + 27) * (W + 27) * eb + 2 * hw,   # read G + hr, write hr
+        # one launch = all n_iter iterations of a patch: SURVEY 8d's per-iteration bytes (read + write hr, read the LR samples)
+        "k_ibp_patch": n_iter * (2 * hw + lrn),
     }.get(name)
+
+
+def workload(synth, name, batch, iters):
+    """(f, lr_hw, shifts, psf, B, n_iter, description) of a named workload."""
+    if name == "c2":
+        return (4, (64, 64), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1024, iters or 80,
+                "C2: x4 multi-frame SR of 64x64 LR patches -> 256x256 HR, N=16 frames (all 4x4 sub-pixel phases), "
+                "7x7 Gaussian PSF, shift_and_add + ibp(80 it, step 0.5)")
+    if name == "c3_mono":  # mono_cal_target/run_sr.py:50-66: 5 frames, nominal +-0.5 px, f=2, 80 iterations
+        return (2, (1536, 2048), synth.NOMINAL_5, synth.gaussian_psf(), batch or 1, iters or 80,
+                "C3-mono: the reference's mono_cal_target shape, 1536x2048 LR -> 3072x4096, N=5 nominal shifts, Gaussian PSF")
+    if name == "c3_rgb":   # rgb_cal_target/run_sr.py:49-63: 4 frames, measured shifts, f=2, 50 iterations
+        return (2, (768, 1024), synth.MEASURED_4, synth.asymmetric_psf(), batch or 1, iters or 50,
+                "C3-rgb: the reference's rgb_cal_target shape, 768x1024 LR -> 1536x2048, N=4 measured shifts, asymmetric PSF")
+    if name == "c3_f4":    # SURVEY.md 8d C3: "plus f=4 variant 768x1024 -> 3072x4096"
+        return (4, (768, 1024), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1, iters or 80,
+                "C3-f4: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all 4x4 sub-pixel phases), Gaussian PSF")
+    raise ValueError(name)
+
+
+def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, allmax=None, profile=True, world=1):
+    """warmup + `steps` timed reconstructions (SAA + IBP) of one workload, inputs resident in HBM; then one extra, untimed step
+    with HIP events around every fused-path launch for the iteration-level roofline:
+        frac = (8 + 4 N / f^2) B H W bytes [SURVEY 8d, eb = 4; 2 eb + eb N / f^2 in general]  /  kernel time per iteration  /  8 TB/s
+    where the kernel time per iteration = sum over the kernels launched once per iteration of their mean duration, plus
+    (duration / n_iter) of a kernel that runs all iterations in one launch (k_ibp_patch)."""
+    f, lr_hw, shifts, psf, B, n_iter, desc = wl
+    N, (h, w) = len(shifts), lr_hw
+    H, W = h * f, w * f
+    lr, _ = make_inputs(S, synth, B, f, lr_hw, shifts, psf, n_unique=min(32, B), prec=prec, seed_base=seed_base)
+    torch.cuda.synchronize()
+
+    def one_step():
+        saa = S.shift_and_add_batched(lr, shifts, f, precision=prec)
+        return S.ibp_batched(lr, shifts, psf, saa, f, n_iter, 0.5, precision=prec, out=saa)
+
+    sync = barrier or torch.cuda.synchronize
+    for _ in range(warmup):
+        hr, errs = one_step()
+    path = S.last_path()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hr, errs = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if allmax is not None:
+        dt = allmax(dt)
+    out = {"value": world * B * H * W / 1e6 * steps / dt, "ms_per_step": dt / steps * 1e3, "path": path, "B": B, "N": N, "f": f,
+           "lr_hw": [h, w], "n_iter": n_iter, "desc": desc, "lr": lr,
+           "sane": bool(torch.isfinite(hr).all().item()) and float(errs[:, -1].mean().item()) < float(errs[:, 0].mean().item())}
+    if not profile:
+        return out
+    lib.srx_profile_enable(1)
+    one_step()
+    torch.cuda.synchronize()
+    eb = 4 if prec == "f32" else 8
+    kernels = {}
+    tot, cnt = ctypes.c_double(), ctypes.c_long()
+    for kid in range(lib.srx_profile_kernel_count()):
+        if lib.srx_profile_get(kid, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value:
+            kernels[lib.srx_profile_kernel_name(kid).decode()] = {"launches": cnt.value, "total_ms": round(tot.value, 3),
+                                                                  "avg_us": round(tot.value / cnt.value * 1e3, 2)}
+    lib.srx_profile_enable(0)
+    per_iter = {k: v["avg_us"] for k, v in kernels.items() if v["launches"] == n_iter and k != "k_ibp_patch"}
+    if "k_ibp_patch" in kernels:  # all iterations of a patch in one launch
+        per_iter["k_ibp_patch"] = kernels["k_ibp_patch"]["total_ms"] * 1e3 / n_iter
+    out["kernels"] = kernels
+    if per_iter:
+        t_iter_us = sum(per_iter.values())
+        it_bytes = (2 * eb + eb * N / (f * f)) * B * H * W
+        dom = max(per_iter, key=per_iter.get)
+        nbytes = kernel_model_bytes(dom, B, N, h, w, f, eb, n_iter)
+        out["iteration"] = {"algorithmic_bytes": it_bytes, "kernels": {k: round(v, 2) for k, v in sorted(per_iter.items())},
+                            "kernel_time_us": round(t_iter_us, 2), "achieved": round(it_bytes / (t_iter_us * 1e-6) / 1e9, 1),
+                            "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["dominant"] = {"kernel": dom, "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": nbytes,
+                           "achieved": round(nbytes / (kernels[dom]["avg_us"] * 1e-6) / 1e9, 1) if nbytes else None,
+                           "frac": round(nbytes / (kernels[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if nbytes else None}
+    return out
 
 
 def cpu_baseline(synth, f, lr_hw, shifts, psf, n_iter, step):
@@ -112,8 +194,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
-    ap.add_argument("--iters", type=int, default=80, help="IBP iterations (reference default 80)")
+    ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: 1024 patches for c2, 1 frame for c3_*)")
+    ap.add_argument("--iters", type=int, default=0, help="IBP iterations (default: the reference's 80; 50 for c3_rgb)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_rgb", "c3_f4"],
                     help="c2 (default, the headline): 1024 x4 patches, N=16 phases; c3_mono / c3_rgb: the reference's own "
@@ -121,6 +203,7 @@ def main():
                          "c3_f4: the x4 variant of SURVEY 8d, 768x1024 -> 3072x4096, all 16 phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (f64 and the c3 shapes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,94 +229,61 @@ def main():
 
     prec = args.precision
     S.set_precision(prec)
-    f, lr_hw, n_iter, step = 4, (64, 64), args.iters, 0.5
-    shifts = synth.phase_shifts(4)
-    psf = synth.gaussian_psf()
-    B = args.batch
-    wl_name = ("C2: x4 multi-frame SR of 64x64 LR patches -> 256x256 HR, N=16 frames (all 4x4 sub-pixel phases), "
-               "7x7 Gaussian PSF, shift_and_add + ibp(80 it, step 0.5)")
-    if args.workload == "c3_mono":   # mono_cal_target/run_sr.py:50-66: 5 frames, nominal +-0.5 px, f=2, 80 iterations
-        f, lr_hw, shifts, B = 2, (1536, 2048), synth.NOMINAL_5, (args.batch if args.batch != 1024 else 1)
-        wl_name = "C3-mono: the reference's mono_cal_target shape, 1536x2048 LR -> 3072x4096, N=5 nominal shifts, Gaussian PSF"
-    elif args.workload == "c3_rgb":  # rgb_cal_target/run_sr.py:49-63: 4 frames, measured shifts, f=2, 50 iterations
-        f, lr_hw, shifts, B = 2, (768, 1024), synth.MEASURED_4, (args.batch if args.batch != 1024 else 1)
-        psf = synth.asymmetric_psf()
-        n_iter = args.iters if args.iters != 80 else 50
-        wl_name = "C3-rgb: the reference's rgb_cal_target shape, 768x1024 LR -> 1536x2048, N=4 measured shifts, asymmetric PSF"
-    elif args.workload == "c3_f4":   # "plus f=4 variant 768x1024 -> 3072x4096"
-        f, lr_hw, shifts, B = 4, (768, 1024), synth.phase_shifts(4), (args.batch if args.batch != 1024 else 1)
-        wl_name = "C3-f4: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all 4x4 sub-pixel phases), Gaussian PSF"
-    N = len(shifts)
-    h, w = lr_hw
+    lib = _lib.load()
+    wl = workload(synth, args.workload, args.batch, args.iters)
+    f, lr_hw, shifts, psf, B, n_iter, wl_name = wl
+    N, (h, w), step = len(shifts), lr_hw, 0.5
     H, W = h * f, w * f
-
-    lr, _ = make_inputs(S, synth, B, f, lr_hw, shifts, psf, n_unique=min(32, B), prec=prec, seed_base=1000 * (rank + 1))
-    torch.cuda.synchronize()
-
-    def one_step():
-        saa = S.shift_and_add_batched(lr, shifts, f, precision=prec)
-        hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n_iter, step, precision=prec, out=saa)
-        return hr, errs
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        hr, errs = one_step()
-    path = S.last_path()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hr, errs = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+    def allmax(dt):
+        if dist is None:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    hr_mp = world * B * H * W / 1e6
-    value = hr_mp * args.steps / dt
-    sane = bool(torch.isfinite(hr).all().item()) and float(errs[:, -1].mean().item()) < float(errs[:, 0].mean().item())
+        return float(t.item())
 
-    # ---- roofline leg: one extra, untimed step with HIP events around every fused-path launch ----
-    roofline, kernels = None, {}
-    if rank == 0 and not args.no_roofline:
-        lib = _lib.load()
-        lib.srx_profile_enable(1)
-        one_step()
-        torch.cuda.synchronize()
-        eb = 4 if prec == "f32" else 8
-        tot, cnt = ctypes.c_double(), ctypes.c_long()
-        for kid in range(lib.srx_profile_kernel_count()):
-            _lib.check(lib.srx_profile_get(kid, ctypes.byref(tot), ctypes.byref(cnt)), "srx_profile_get")
-            if cnt.value:
-                kernels[lib.srx_profile_kernel_name(kid).decode()] = {"launches": cnt.value, "total_ms": round(tot.value, 3),
-                                                                      "avg_us": round(tot.value / cnt.value * 1e3, 2)}
-        lib.srx_profile_enable(0)
-        ibp_k = {k: v for k, v in kernels.items() if kernel_model_bytes(k, B, N, h, w, f, eb)}
-        # every kernel that runs once per IBP iteration (launch count = n_iter) counts toward the iteration time
-        per_iter = {k: v for k, v in kernels.items() if v["launches"] == n_iter}
-        if ibp_k:
-            dom = max(ibp_k, key=lambda k: ibp_k[k]["total_ms"])
-            nbytes = kernel_model_bytes(dom, B, N, h, w, f, eb)
-            ach = nbytes / (ibp_k[dom]["avg_us"] * 1e-6) / 1e9
-            t_iter_us = sum(v["total_ms"] for v in per_iter.values()) * 1e3 / n_iter
-            it_bytes = (2 * eb + eb * N / (f * f)) * B * H * W  # 8 + 4N/f^2 B per HR px per iteration (f32)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": ibp_k[dom]["avg_us"],
-                        "iteration": {"algorithmic_bytes": it_bytes, "kernels": sorted(per_iter),
-                                      "kernel_time_us": round(t_iter_us, 1),
-                                      "achieved": round(it_bytes / (t_iter_us * 1e-6) / 1e9, 1),
-                                      "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
-            tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC pass (tools/collect_pmc.py), per launch
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                if tj.get("workload") == f"C2:B={B}" and dom in tj.get("kernels", {}):
-                    roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
+    m = measure(S, synth, lib, wl, prec, args.steps, args.warmup, 1000 * (rank + 1), barrier, allmax,
+                profile=(rank == 0 and not args.no_roofline), world=world)
+    lr, path, kernels = m["lr"], m["path"], m.get("kernels", {})
+
+    # ---- roofline (contract field): the ITERATION-level figure of SURVEY 8d; the per-kernel view sits in dominant_kernel ----
+    roofline = None
+    if "iteration" in m:
+        it = m["iteration"]
+        roofline = {"bound": "hbm", "achieved": it["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it["frac"],
+                    "traffic": None, "traffic_ratio": None, "algorithmic_bytes_per_iteration": it["algorithmic_bytes"],
+                    "kernel_time_per_iteration_us": it["kernel_time_us"], "iteration_kernels_us": it["kernels"],
+                    "dominant_kernel": m.get("dominant"),
+                    "note": "achieved = (8 + 4N/f^2) B per HR pixel and iteration (SURVEY 8d) x B H W / kernel time per iteration "
+                            "(HIP events on the launch stream); traffic = PMC bytes of the iteration kernels per iteration"}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (tools/collect_traffic.py)
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            if tj.get("workload") == f"{args.workload}:B={B}:{prec}":
+                tr = sum(tj["kernels"][k]["hbm_bytes_per_iteration"] for k in it["kernels"] if k in tj["kernels"])
+                if tr and all(k in tj["kernels"] for k in it["kernels"]):
+                    roofline["traffic"] = tr
+                    roofline["traffic_ratio"] = round(tr / it["algorithmic_bytes"], 3)
+
+    # ---- secondary legs, timed in this same run (rank 0, N = 1): the reference's precision and its own full-frame shapes ----
+    legs = None
+    if rank == 0 and world == 1 and not args.no_roofline and not args.no_secondary and args.workload == "c2":
+        legs = {}
+        for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c3_mono", "c3_mono", "f32", None), ("c3_rgb", "c3_rgb", "f32", None),
+                                      ("c3_f4", "c3_f4", "f32", None), ("c3_mono_x8", "c3_mono", "f32", 8)):
+            lw = workload(synth, wname, lb if lb else (args.batch if wname == "c2" and args.batch else None), args.iters if wname == "c2" else None)
+            r = measure(S, synth, lib, lw, lprec, 2, 1, 7000)
+            legs[tag] = {"workload": r["desc"], "dtype": lprec, "batch": r["B"], "n_iter": r["n_iter"], "path": r["path"],
+                         "value": round(r["value"], 2), "unit": "HR-MP/s", "ms_per_step": round(r["ms_per_step"], 3), "sane": r["sane"],
+                         "iteration": r.get("iteration")}
+            del r
+            torch.cuda.empty_cache()
+        S.set_precision(prec)
 
     # ---- secondary figures: shift_and_add alone, and the same step from / to HOST buffers ----
     extras = None
@@ -272,6 +322,10 @@ def main():
                   "host_buffers_hr_mp_per_s": round(B * H * W / 1e6 / t_host, 1), "host_buffers_ms": round(t_host * 1e3, 3),
                   "host_buffers_note": "pinned host LR in, pinned host HR out, H2D + step + D2H on one stream; never the headline value"}
         del lr_host, hr_host, lr_d, saa_d, hr_d
+    if extras is not None and legs is not None:
+        extras.update(legs)
+    elif legs is not None:
+        extras = legs
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -284,13 +338,13 @@ def main():
     if rank == 0:
         line = {
             "metric": f"HR megapixels/sec at x{f} upscale (SAA + {n_iter}-iteration IBP reconstruction)",
-            "value": round(value, 2), "unit": "HR-MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(m["value"], 2), "unit": "HR-MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(m["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": prec, "data": "synthetic",
             "config": {"workload": wl_name,
                        "patches_per_gpu": B, "global_patches": world * B, "factor": f, "frames": N, "lr_patch": [h, w],
                        "n_iter": n_iter, "path": path, "parallelism": f"patch-sharded x{world}, no collective"},
-            "hr_mp_iter_per_s": round(value * n_iter, 1), "sane": sane,
+            "hr_mp_iter_per_s": round(m["value"] * n_iter, 1), "sane": m["sane"],
             "roofline": roofline, "kernels": kernels, "secondary": extras, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

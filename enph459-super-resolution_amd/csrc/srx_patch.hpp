@@ -306,10 +306,10 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
 // ---- backward chain of one block ------------------------------------------------------------------------------------
 // a[] in: G samples of this block; gm1 / gp1 / gp2: G just before / after the block (halo exchange done by the caller);
 // gtop: G[-ex] of the line (first block).  out: corr = blur'( crop P( FIR_b G ) ).  Two workgroup barriers.
-template <typename F>
+template <typename F, typename P>
 __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool first, bool last, float *Rown, const float *Rprev,
                                           const float *Rnext, int s1, int s6, int lane, const f8 wfb, const f8 kt, float gm1, float gp1,
-                                          float gp2, float gtop, F mid)
+                                          float gp2, float gtop, F mid, P post)
 {
     const float z = PZ;
     const float w0 = wfb[4], w1 = wfb[5], w2 = wfb[6], w3 = wfb[7];
@@ -350,7 +350,6 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     Rown[s6 + 256 + lane] = a[62];
     Rown[s6 + 320 + lane] = a[63];
     __syncthreads();
-    mid();        // caller's hook (loads to have in flight during the blur)
     float e[70];  // the block's coefficients with three on either side (zero outside the image)
     e[0] = e[1] = e[2] = e[67] = e[68] = e[69] = 0.f;
     if (!last) {
@@ -369,12 +368,17 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     for (int i = 0; i < 64; i++)
         e[3 + i] = a[i];
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        float acc = kt[0] * e[i];
+    for (int q = 0; q < 4; q++) {
+        mid(q);  // caller's hook before every quarter of the blur (loads / stores to overlap with it)
 #pragma unroll
-        for (int u = 1; u < 7; u++)
-            acc = fmaf(kt[u], e[i + u], acc);
-        out[i] = acc;
+        for (int i = 16 * q; i < 16 * q + 16; i++) {
+            float acc = kt[0] * e[i];
+#pragma unroll
+            for (int u = 1; u < 7; u++)
+                acc = fmaf(kt[u], e[i + u], acc);
+            out[i] = post(i, acc);  // caller's epilogue (identity, or the IBP update)
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -452,25 +456,18 @@ __global__ void __launch_bounds__(1024)
     // 0/1 count map of a full phase grid: this wave's 64 row bits (row layout: bit = lane) and 64 column bits
     const unsigned long long rmask = C01 ? pa.ry[s] : 0ull, cmask = C01 ? pa.rx[u] : 0ull;
 
-    // The state lives in hr_out between iterations: every iteration reads its block at the top (an L2 hit: this wave wrote it)
-    // and writes the updated block at the bottom.  Carrying the 64 registers across the loop edge instead made the register
-    // allocator spill ~180 values per iteration; the copy in hr_out is needed anyway (the pre-update state for the update).
-    if (hr_in != hr_out) {
+    // The state (this wave's 64 x 64 block of hr, column layout) stays in registers from one iteration's update to the next
+    // iteration's blur; every iteration also parks it in hr_out, where the update re-reads it 16 rows at a time (the register
+    // file holds the state OR the working plane, not both).
+    float a[64];
+    {
         const int l4 = (tid0 & 63) * 4;
 #pragma unroll
-        for (int i0 = 0; i0 < 64; i0 += 16) {
-            float t[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                t[i] = fused::buf_load<float>(rs_in, l4 + (i & 3) * PN * 4, cb0 + ((i0 + i) >> 2) * PN * 16);
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                fused::buf_store<float>(t[i], rs_out, l4 + (i & 3) * PN * 4, cb0 + ((i0 + i) >> 2) * PN * 16);
-        }
+        for (int i = 0; i < 64; i++)
+            a[i] = fused::buf_load<float>(rs_in, l4 + (i & 3) * PN * 4, cb0 + (i >> 2) * PN * 16);
     }
-
     for (int it = 0; it < n_iter; it++) {
-        float a[64], r[64];
+        float r[64];
         // everything derived from the lane index is re-derived per iteration from an opaque copy: hoisted out of the loop, the
         // ~45 lane-dependent addresses and predicates do not fit beside the working plane and were spilled, one scratch
         // round trip per use
@@ -490,7 +487,7 @@ __global__ void __launch_bounds__(1024)
         // ================= stage A: column layout, lane = column 64 u + lane, a[i] = row 64 s + i =================
 #pragma unroll
         for (int i = 0; i < 64; i++)
-            a[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
+            fused::buf_store<float>(a[i], rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
         blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(1);
@@ -655,6 +652,13 @@ __global__ void __launch_bounds__(1024)
                     gexx = src[-1];
             }
         }
+        // ---- MSE trace of this iteration (before the update): per-wave sums now, added up in a fixed order by thread 0 behind the
+        // next barrier (no barrier of its own)
+        if (errors) {
+            const double ws = wave_sum((double)sq);
+            if (lane == 0)
+                part[wave] = ws;
+        }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(9);
         // ---- H-bwd
@@ -663,10 +667,17 @@ __global__ void __launch_bounds__(1024)
             Rown[SLOT1 + 64 + lane] = r[1];
             Rown[SLOT1 + 128 + lane] = r[63];
             __syncthreads();
+            if (errors && tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    t += part[i];
+                errors[(size_t)b * n_iter + it] = (t + Vtot[b]) * scale;
+            }
             const float gtop = exx ? gexx : r[0];
             const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];
             const float gp1 = u == 3 ? 0.f : Rrt[SLOT1 + lane], gp2 = u == 3 ? 0.f : Rrt[SLOT1 + 64 + lane];
-            bwd_chain(r, a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop, [] {});
+            bwd_chain(r, a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop, [](int) {}, [](int, float v) { return v; });
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(10);
@@ -677,7 +688,7 @@ __global__ void __launch_bounds__(1024)
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(12);
         // ================= stage C: column layout again, r[i] = row 64 s + i (row 63 of s == 3: the wrapped row -1) =================
-        float hv[16], hw[16];  // the parked state, 16 rows at a time; the first batch is in flight during the last blur
+        float hv[16], hw[16];  // the parked state, 16 rows at a time
         {
             if (exy && s == 3) {
                 rowbuf[64 * u + lane] = r[63];
@@ -690,49 +701,34 @@ __global__ void __launch_bounds__(1024)
             const float gtop = exy ? rowbuf[64 * u + lane] : r[0];
             const float gm1 = s == 0 ? gtop : Rup[SLOT0 + 128 + lane];
             const float gp1 = s == 3 ? 0.f : Rdn[SLOT0 + lane], gp2 = s == 3 ? 0.f : Rdn[SLOT0 + 64 + lane];
-            bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, [&] {
+            bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop,
+                      [&](int q) {
+                          // the parked state in 16-row batches, two in flight: batch q is consumed by quarter q of the blur
+                          auto load16 = [&](float(&ld)[16], int bq) {
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    hv[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
-            });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        SRX_PSTAMP(13);
-        // ---- update: the new state
-        {
-            // clip(hr + step * corr / N, 0, 255) as one v_med3_f32 (compare + select pairs made the compiler keep 64 lane masks)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float(&cur)[16] = (q & 1) ? hw : hv;
-                float(&nxt)[16] = (q & 1) ? hv : hw;
-                if (q < 3) {
-#pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        nxt[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (4 * (q + 1) + (i >> 2)) * PN * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    fused::buf_store<float>(__builtin_amdgcn_fmed3f(fmaf(a[16 * q + i], sn, cur[i]), 0.f, 255.f), rs_out, l4 + (i & 3) * PN * 4,
-                                            cbl + (4 * q + (i >> 2)) * PN * 16);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                              for (int i = 0; i < 16; i++)
+                                  ld[i] = fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (4 * bq + (i >> 2)) * PN * 16);
+                          };
+                          if (q == 0)
+                              load16(hv, 0), load16(hw, 1);
+                          else if (q == 1)
+                              load16(hv, 2);
+                          else if (q == 2)
+                              load16(hw, 3);
+                      },
+                      [&](int i, float corr) {
+                          // the update, fused into the blur's epilogue: hr <- clip(hr + step * corr / N, 0, 255), one v_med3_f32
+                          return __builtin_amdgcn_fmed3f(fmaf(corr, sn, ((i >> 4) & 1) ? hw[i & 15] : hv[i & 15]), 0.f, 255.f);
+                      });
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(14);
-        // ---- MSE trace of this iteration (before the update): fixed summation order
-        if (errors) {
-            const double ws = wave_sum((double)sq);
-            if (lane == 0)
-                part[wave] = ws;
-            __syncthreads();
-            if (tid == 0) {
-                double t = 0.0;
+    }
+    {
+        const int l4 = (tid0 & 63) * 4;
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    t += part[i];
-                errors[(size_t)b * n_iter + it] = (t + Vtot[b]) * scale;
-            }
-        }
+        for (int i = 0; i < 64; i++)
+            fused::buf_store<float>(a[i], rs_out, l4 + (i & 3) * PN * 4, cb0 + (i >> 2) * PN * 16);
     }
 }
 

@@ -36,8 +36,14 @@ def test_two_ranks_on_one_gpu():
 
 
 def test_single_rank_line_has_roofline_and_cpu_baseline():
-    line = _bench({}, [sys.executable], ["--steps", "1", "--warmup", "1", "--batch", "64", "--iters", "8"])
-    assert line["n_gpus"] == 1 and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
-    assert line["roofline"]["kernel"] in line["kernels"] and line["roofline"]["peak"] == 8000.0
+    line = _bench({}, [sys.executable], ["--steps", "1", "--warmup", "1", "--batch", "64", "--iters", "8", "--no-secondary"])
+    rf = line["roofline"]
+    assert line["n_gpus"] == 1 and rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
+    # the contract field is the ITERATION-level figure of SURVEY 8d: (8 + 4 N / f^2) B per HR pixel / kernel time per iteration
+    assert rf["algorithmic_bytes_per_iteration"] == (8 + 4 * 16 / 16) * 64 * 256 * 256
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_iteration"] / (rf["kernel_time_per_iteration_us"] * 1e-6) / 1e9) < 0.01 * rf["achieved"]
+    assert abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-3
+    assert set(rf["iteration_kernels_us"]) <= set(line["kernels"]) and rf["dominant_kernel"]["kernel"] in line["kernels"]
+    assert line["config"]["path"] == "patch" and "k_ibp_patch" in line["kernels"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0
     assert line["cpu_baseline"]["psnr_gpu_vs_cpu_db"] > 90

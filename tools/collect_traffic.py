@@ -8,7 +8,10 @@ exactly half of the bytes actually fetched -- calibrated here on our own access 
 k_blur_pad reads one 268 435 456-byte plane per launch and FETCH_SIZE says 131 116 KiB = 0.5002 of it, while
 its WRITE_SIZE (262 144 KiB) is exact.  So bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
 
-usage: collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <workload tag> [out.json]
+A kernel that runs all IBP iterations in one launch (k_ibp_patch) is divided by the iteration count of the profiled run, so
+that every entry also carries `hbm_bytes_per_iteration` (what bench.py's roofline.traffic sums).
+
+usage: collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <workload tag> <iters of the run> [out.json]
 """
 import collections
 import csv
@@ -25,7 +28,11 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+PERSISTENT = ("k_ibp_patch",)  # one launch = all iterations
+
+
 def main():
+    iters = int(sys.argv[4])
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"workload": sys.argv[3], "unit": "bytes per launch",
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
@@ -34,9 +41,10 @@ def main():
         if not k.startswith("k_"):
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-        out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
-                             "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-    dst = sys.argv[4] if len(sys.argv) > 4 else "profiles/traffic.json"
+        nb = int((2 * f + w) * 1024)
+        out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": nb,
+                             "hbm_bytes_per_iteration": nb // iters if k in PERSISTENT else nb}
+    dst = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
