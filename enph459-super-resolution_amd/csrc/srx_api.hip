@@ -312,7 +312,7 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
         if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
-            g_last_path = patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f) ? "patch" : "mosaic";
+            g_last_path = (!(flags & SRX_FLAG_TILES) && patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)) ? "patch" : "mosaic";
             return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
         }
         g_last_path = "fused";
@@ -493,12 +493,14 @@ int srx_interleave4_u8(const uint8_t *frames, int B, int h, int w, uint8_t *out,
     int srx_saa_##SFX(const T *lr, int B, int N, int h, int w, const double *sh, int f, T *out, void *ws, size_t wsb,   \
                       srx_stream_t s, unsigned flags)                                                                  \
     {                                                                                                                  \
+        CallFlags cf(flags);                                                                                           \
         return saa_dispatch<T>(lr, B, N, h, w, sh, f, out, ws, wsb, hs(s), flags);                                     \
     }                                                                                                                  \
     int srx_ibp_##SFX(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,       \
                       const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr_out, double *errors,       \
                       void *ws, size_t wsb, srx_stream_t s, unsigned flags)                                            \
     {                                                                                                                  \
+        CallFlags cf(flags);                                                                                           \
         return ibp_dispatch<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr_out, errors, ws, wsb, \
                                hs(s), flags);                                                                          \
     }                                                                                                                  \

@@ -26,6 +26,18 @@ template <typename T> struct KernelArg {
 
 static inline hipStream_t hs(srx_stream_t s) { return (hipStream_t)s; }
 
+// `flags` of the srx_ibp / srx_saa call running on this thread (0 outside one): the SRX_FLAG_DIAG_* path switches are read
+// through this where the decision is made, several layers below the entry point.  Set and cleared by the entry (CallFlags).
+inline unsigned &call_flags()
+{
+    static thread_local unsigned f = 0;
+    return f;
+}
+struct CallFlags {
+    explicit CallFlags(unsigned f) { call_flags() = f; }
+    ~CallFlags() { call_flags() = 0; }
+};
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // bump allocator over the caller's workspace

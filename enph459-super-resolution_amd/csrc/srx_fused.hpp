@@ -92,7 +92,7 @@ template <typename T> static void make_kernel7(const double *k, int kh, int kw, 
     for (int i = 0; i < 49; i++)
         if (std::fabs(c[i]) > amax)
             amax = std::fabs(c[i]), um = i / 7, vm = i % 7;
-    bool sep = amax > 0.0 && !getenv("SRX_NO_SEPARABLE");
+    bool sep = amax > 0.0 && !(call_flags() & SRX_FLAG_DIAG_NO_SEPARABLE);
     double dev = 0.0;
     for (int u = 0; u < 7 && sep; u++)
         for (int v = 0; v < 7; v++)
@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(256)
 template <typename T> static int prefilter2d_fast(T *a, T *scratch, int B, int Hc, int Wc, int mode, hipStream_t st)
 {
     if constexpr (sizeof(T) == 4) {  // (the double tile would not fit the LDS)
-        if (Hc >= 64 && Wc >= 64 && B <= 65535 && !getenv("SRX_NO_PREFILTER_TILE")) {
+        if (Hc >= 64 && Wc >= 64 && B <= 65535 && !(call_flags() & SRX_FLAG_DIAG_NO_PREFILTER_TILE)) {
             SRX_LAUNCH(KID_PREFILTER_TILE, k_prefilter_tile<T>, dim3(cdiv(Wc, 64), cdiv(Hc, 64), B), dim3(256), 0, st, a, scratch, Hc, Wc,
                        mode);
             if (hipMemcpyAsync(a, scratch, (size_t)B * Hc * Wc * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -1341,16 +1341,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int h, int w, int H, int W, in
            align_up((size_t)B * cdiv(H, 16) * cdiv(W, 16) * sizeof(double));  // per-tile MSE partial sums
 }
 
-// SRX_IBP_VARIANT=v1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
-static inline bool use_v1()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SRX_IBP_VARIANT");
-        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
+// SRX_FLAG_DIAG_V1 selects the 8-launch iteration (stand-alone exact prefilter passes); default v2.
+static inline bool use_v1() { return (call_flags() & SRX_FLAG_DIAG_V1) != 0; }
 
 // v2 iteration loop: blur_pad -> fwd_tile -> bwd_tile, lattice-tap tables built once per call
 template <typename T, int F>

@@ -105,7 +105,7 @@ static inline bool plan_axis(int N, const double *sh, int axis, int f, AxisPlan 
 
 static inline bool eligible(int N, int h, int w, const double *sh, int kh, int kw, int H, int W, int f)
 {
-    if (getenv("SRX_NO_MOSAIC") || !fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f) || f < 2)
+    if (!fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f) || f < 2)
         return false;
     AxisPlan a;
     return plan_axis(N, sh, 0, f, a) && plan_axis(N, sh, 1, f, a) && H >= 32 && W >= 32;
@@ -1102,18 +1102,27 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if constexpr (sizeof(T) == 4) {
         // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp).
         // Its transposed far-field operands take the places of the planes it does not need (G and the blurred plane).
-        if (patch::eligible(4, N, H, W, sh, k, kh, kw, f)) {
+        if (!(call_flags() & SRX_FLAG_TILES) && patch::eligible(4, N, H, W, sh, k, kh, kw, f)) {
             return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
                                   errors, st);
         }
     }
     constexpr int TS = TileCfg<T>::T_HR;
-    const int dbg = getenv("SRX_DBG") ? atoi(getenv("SRX_DBG")) : 0;  // timing ablations only (results are wrong)
-    const size_t dbg_lds = getenv("SRX_DBG_LDS") ? (size_t)atoi(getenv("SRX_DBG_LDS")) : 0;  // extra LDS: caps blocks per CU
+    // timing ablations (results are wrong / an occupancy cap): compile-time only, -DSRX_ABLATE=<bits> -DSRX_ABLATE_LDS=<bytes>
+#ifdef SRX_ABLATE
+    const int dbg = SRX_ABLATE;
+#else
+    const int dbg = 0;
+#endif
+#ifdef SRX_ABLATE_LDS
+    const size_t dbg_lds = SRX_ABLATE_LDS;
+#else
+    const size_t dbg_lds = 0;
+#endif
     const dim3 bgrid(cdiv(W, SRX_BT_W), cdiv(H, SRX_BT_H), B), bblk(64, 4);
     const dim3 fgrid(cdiv(Wg, TS), cdiv(Hg, zero ? FwdRows<T, true>::v : TS), B), wgrid(cdiv(W, TS), cdiv(H, TS), B);
     // delta = 0: blur and forward map in one kernel over image tiles (no blurred plane); SRX_NO_ZERO_FUSE keeps the two kernels
-    const bool zfuse = zero && !getenv("SRX_NO_ZERO_FUSE");
+    const bool zfuse = zero && !(call_flags() & SRX_FLAG_DIAG_NO_ZERO_FUSE);
     const int nblk = zfuse ? (int)(bgrid.x * bgrid.y) : (int)(fgrid.x * fgrid.y);  // MSE partial sums per item
     for (int it = 0; it < n_iter; it++) {
         const T *cur = it == 0 ? hr_init : hr;
@@ -1158,7 +1167,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
 
 static inline bool saa_eligible(int N, int h, int w, const double *sh, int f)
 {
-    if (getenv("SRX_NO_MOSAIC") || !fused::saa_eligible(N, h, w, sh, f) || f < 2 || f > 4 || h < 8 || w < 8)
+    if (!fused::saa_eligible(N, h, w, sh, f) || f < 2 || f > 4 || h < 8 || w < 8)
         return false;
     AxisPlan a;
     return plan_axis(N, sh, 0, f, a) && plan_axis(N, sh, 1, f, a);

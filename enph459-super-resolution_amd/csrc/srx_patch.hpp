@@ -117,7 +117,7 @@ static inline bool axis_ok(const mosaic::AxisPlan &pl, int N, int f)
 
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
-    if (getenv("SRX_NO_PATCH") || elem_bytes != 4 || H != PN || W != PN || f < 2)
+    if (elem_bytes != 4 || H != PN || W != PN || f < 2)
         return false;
     mosaic::AxisPlan py, px;
     if (!mosaic::plan_axis(N, sh, 0, f, py) || !mosaic::plan_axis(N, sh, 1, f, px))

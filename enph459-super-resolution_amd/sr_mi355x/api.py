@@ -27,7 +27,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME  # noqa: F401  (re-exported)
+from ._lib import (FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME, FLAG_TILES, FLAG_DIAG_NO_ZERO_FUSE,  # noqa: F401  (re-exported)
+                   FLAG_DIAG_NO_SEPARABLE, FLAG_DIAG_NO_PREFILTER_TILE, FLAG_DIAG_V1)
 
 _PRECISION = os.environ.get("SRX_PRECISION", "f32")
 _TORCH_DT = {"f32": torch.float32, "f64": torch.float64}

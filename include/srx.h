@@ -56,11 +56,19 @@ typedef enum {
 #define SRX_FLAG_COMPOSED 1u /* force the literal per-frame composition of the primitives */
 #define SRX_FLAG_FUSED 2u    /* require a fused path; SRX_E_UNSUPPORTED if not eligible */
 #define SRX_FLAG_PER_FRAME 4u /* fused, but never the "mosaic" (common-fraction, depth-to-space) formulation */
+#define SRX_FLAG_TILES 8u     /* mosaic formulation, but never the patch-resident kernel (one workgroup per 256x256 HR patch) */
+/* Diagnostic path switches: each selects between implementations that the tests hold to the same results.  They are call
+ * arguments (no environment variable alters what a call computes). */
+#define SRX_FLAG_DIAG_NO_ZERO_FUSE 0x100u      /* delta = 0: separate blur and index-map kernels */
+#define SRX_FLAG_DIAG_NO_SEPARABLE 0x200u      /* 7x7 form of a rank-1 PSF */
+#define SRX_FLAG_DIAG_NO_PREFILTER_TILE 0x400u /* line prefilter kernels for float planes */
+#define SRX_FLAG_DIAG_V1 0x800u                /* per-frame fused path with stand-alone prefilter passes (8 launches / iteration) */
 
 int srx_version(void);
 const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
- * "mosaic" (all shifts share one sub-pixel fraction: dense depth-to-space formulation), "fused"
+ * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch), "mosaic" (all shifts
+ * share one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "fused"
  * (per-frame tile kernels), "composed" (primitives, frame by frame). */
 const char *srx_last_path(void);
 

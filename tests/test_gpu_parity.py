@@ -2,7 +2,7 @@
 (1) golden vectors made by the reference's own functions (tests/golden, tools/make_golden.py)
 and (2) the CPU oracle on seeded inputs.  Tolerances (DN on 0..255 data):
     f64 : 1e-9 primitives, 1e-8 after 80 IBP iterations           (the reference's precision)
-    f32 : 2e-3 primitives, 1e-2 after 80 IBP iterations, PSNR(build, ref) > 90 dB and
+    f32 : 5e-4 primitives, 1e-3 after 80 IBP iterations (measured: 1.2e-4 ... 2.2e-4), PSNR(build, ref) > 90 dB and
           |PSNR(build, truth) - PSNR(ref, truth)| < 0.01 dB         (the north-star bar)
     index maps (decimate / zero-insert / Bayer red / quantiser): bit-exact.
 """
@@ -18,8 +18,8 @@ torch = pytest.importorskip("torch")
 import sr_mi355x as S  # noqa: E402
 from sr_mi355x import synth  # noqa: E402
 
-PRIM_TOL = {"f64": 1e-9, "f32": 2e-3}
-IBP_TOL = {"f64": 1e-8, "f32": 1e-2}
+PRIM_TOL = {"f64": 1e-9, "f32": 5e-4}
+IBP_TOL = {"f64": 1e-8, "f32": 1e-3}
 ERR_RTOL = {"f64": 1e-10, "f32": 2e-5}
 
 
@@ -339,6 +339,9 @@ def test_full_size_ibp_fixed_point():
     S.set_precision("f32")
     f, shifts, psf, x, lr = _full_c2_batch(1024)
     hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
+    assert S.last_path() == "patch"
+    assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
+    hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5, flags=S.FLAG_TILES)
     assert S.last_path() == "mosaic"
     assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
     # the reference's largest shape: N = 5 nominal shifts, f = 2, 1536x2048 -> 3072x4096, one item
@@ -351,8 +354,8 @@ def test_full_size_ibp_fixed_point():
 
 
 def test_full_size_paths_agree_and_items_are_independent():
-    """Headline patch size, noisy frames: the mosaic path, the per-frame fused path and (on a few items) the composed
-    path give the same result; an item's result does not depend on its batch."""
+    """Headline patch size, noisy frames: the patch-resident kernel, the mosaic tile kernels, the per-frame fused path and (on a
+    few items) the composed path give the same result; an item's result does not depend on its batch."""
     S.set_precision("f32")
     f, shifts, psf, x, lr = _full_c2_batch(96)
     gen = torch.Generator(device="cuda")
@@ -363,7 +366,11 @@ def test_full_size_paths_agree_and_items_are_independent():
     saa_p = S.shift_and_add_batched(lr, shifts, f, flags=S.FLAG_PER_FRAME)
     assert float((saa - saa_p).abs().max()) < 2e-3
     hr_m, e_m = S.ibp_batched(lr, shifts, psf, saa, f, 8, 0.5)
+    assert S.last_path() == "patch"
+    hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 8, 0.5, flags=S.FLAG_TILES)
     assert S.last_path() == "mosaic"
+    assert float((hr_m - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(e_m.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
     hr_p, e_p = S.ibp_batched(lr, shifts, psf, saa, f, 8, 0.5, flags=S.FLAG_PER_FRAME)
     assert S.last_path() == "fused"
     assert float((hr_m - hr_p).abs().max()) < 5e-3
@@ -456,7 +463,7 @@ def test_batches_beyond_one_launch():
 
 def test_delta_zero_fused_forward_matches_two_kernel_form(prec):
     """delta = 0 (the reference's nominal +-0.5 px at f = 2): the forward kernel that blurs its own image tiles
-    (k_blurfwd_zero) against blur + index-map kernels (SRX_NO_ZERO_FUSE=1), on an image with ragged edge tiles."""
+    (k_blurfwd_zero) against blur + index-map kernels (SRX_FLAG_DIAG_NO_ZERO_FUSE), on an image with ragged edge tiles."""
     gen = torch.Generator(device="cuda")
     gen.manual_seed(5)
     dt = torch.float64 if prec == "f64" else torch.float32
@@ -465,10 +472,137 @@ def test_delta_zero_fused_forward_matches_two_kernel_form(prec):
     for psf in (synth.gaussian_psf(), synth.asymmetric_psf()):
         hr_a, e_a = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5)
         assert S.last_path() == "mosaic"
-        os.environ["SRX_NO_ZERO_FUSE"] = "1"
-        try:
-            hr_b, e_b = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5)
-        finally:
-            del os.environ["SRX_NO_ZERO_FUSE"]
+        hr_b, e_b = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5, flags=S.FLAG_DIAG_NO_ZERO_FUSE)
+        assert S.last_path() == "mosaic"
         assert float((hr_a - hr_b).abs().max()) <= (1e-10 if prec == "f64" else 2e-4)
         np.testing.assert_allclose(e_a.cpu().numpy(), e_b.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The patch-resident kernel (csrc/srx_patch.hpp): one workgroup per 256 x 256 HR patch, all iterations in one launch
+# ---------------------------------------------------------------------------------------------------------
+def _patch_case(f, shifts, n_items, integer_lr=True, seed=300):
+    from oracle import sr_oracle as O
+    psf = synth.gaussian_psf()
+    O.set_threads(8)
+    try:
+        truths = [synth.truth_image(256, 256, seed=seed + i) for i in range(n_items)]
+        lr = np.stack([np.stack([O.forward_model(t, psf, s, f) for s in shifts]) for t in truths])
+        lr = np.stack([synth.sensor_frames(x, seed=seed + 50 + i) for i, x in enumerate(lr)]) if integer_lr else \
+            np.clip(lr + np.random.default_rng(seed).normal(0, 1, lr.shape), 0, 255)  # rep-averaged style: not integers
+        saa = np.stack([O.shift_and_add(list(x), shifts, f) for x in lr])
+    finally:
+        O.set_threads(1)
+    return psf, lr, saa
+
+
+PATCH_CFGS = {
+    # name: (factor, shifts, integer-valued LR).  "dup": two frames on one phase -> the count map is not a 0/1 product
+    "x4_grid": (4, synth.phase_shifts(4), True),
+    "x4_grid_float": (4, synth.phase_shifts(4), False),
+    "x2_grid": (2, synth.phase_shifts(2), True),
+    "x4_dup": (4, synth.phase_shifts(4) + [synth.phase_shifts(4)[5]], True),
+    "x2_half_row": (2, [(0.25, 0.25), (0.25, -0.25)], True),
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(PATCH_CFGS))
+def test_patch_kernel_vs_oracle(cfg):
+    """k_ibp_patch against the oracle after 1, 2, 10 and 80 iterations (HR state and MSE trace), and against the tile kernels:
+    full phase grids (uint8 mosaic + 0/1 count masks), non-integer frames (float mosaic), frames sharing a phase (count plane)."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, integer_lr = PATCH_CFGS[cfg]
+    psf, lr, saa = _patch_case(f, shifts, 2, integer_lr)
+    O.set_threads(8)
+    try:
+        for n in (1, 2, 10, 80):
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5)
+            assert S.last_path() == "patch"
+            for i in range(2 if n < 80 else 1):
+                hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
+                close(hr[i].cpu().numpy(), hr_o, IBP_TOL["f32"])
+                np.testing.assert_allclose(errs[i].cpu().numpy(), err_o, rtol=ERR_RTOL["f32"])
+    finally:
+        O.set_threads(1)
+    hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 80, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "mosaic"
+    assert float((hr - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+
+
+def test_patch_kernel_in_place_batches_and_fallbacks():
+    """hr_out aliasing hr_init; a batch equals its items; shapes / PSFs the patch kernel does not take fall back to the tiles."""
+    S.set_precision("f32")
+    f, shifts = 4, synth.phase_shifts(4)
+    psf, lr, saa = _patch_case(f, shifts, 5, seed=340)
+    lr_d, saa_d = torch.from_numpy(lr).cuda().float(), torch.from_numpy(saa).cuda().float()
+    hr, errs = S.ibp_batched(lr_d, shifts, psf, saa_d, f, 12, 0.5)
+    assert S.last_path() == "patch"
+    buf = saa_d.clone()
+    hr2, errs2 = S.ibp_batched(lr_d, shifts, psf, buf, f, 12, 0.5, out=buf)
+    assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
+    one, e1 = S.ibp_batched(lr_d[3:4], shifts, psf, saa_d[3:4], f, 12, 0.5)
+    assert torch.equal(one[0], hr[3]) and torch.equal(e1[0], errs[3])
+    S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # non-separable PSF
+    assert S.last_path() == "mosaic"
+    S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR
+    assert S.last_path() == "mosaic"
+    S.ibp_batched(lr_d[:1].double(), shifts, psf, saa_d[:1].double(), f, 2, 0.5, precision="f64")
+    assert S.last_path() == "mosaic"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Parity holes named by the round-1 review
+# ---------------------------------------------------------------------------------------------------------
+def test_make_gaussian_psf_matches_reference(g_c1):
+    """sr_mi355x.make_gaussian_psf (what run_sr uses; mono_cal_target/run_sr.py:104-111) against the reference's own PSF."""
+    k = np.asarray(S.make_gaussian_psf())
+    assert k.dtype == np.float64 and k.shape == (7, 7) and np.abs(k - g_c1["psf_g"]).max() < 1e-17
+
+
+@pytest.mark.parametrize("cfg", ["mosaic_half", "per_frame"])
+def test_80_iterations_multi_tile(prec, cfg):
+    """80 iterations on a non-square image spanning several tiles, against the oracle: the mosaic tile kernels with a common
+    fraction of 1/2 (in-tile prefilter with truncated warm-ups), and the per-frame fused path on measured shifts."""
+    from oracle import sr_oracle as O
+    O.set_threads(16)
+    try:
+        if cfg == "mosaic_half":
+            f, shifts, psf, (h, w), want, flags = 2, synth.phase_shifts(2), synth.gaussian_psf(), (75, 139), "mosaic", S.FLAG_AUTO
+        else:
+            f, shifts, psf, (h, w), want, flags = 2, synth.MEASURED_4, synth.asymmetric_psf(), (83, 131), "fused", S.FLAG_PER_FRAME
+        truth = synth.truth_image(h * f, w * f, seed=91)
+        lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=92)
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 80, 0.5)
+    finally:
+        O.set_threads(1)
+    hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 80, 0.5, flags=flags)
+    assert S.last_path() == want
+    close(hr[0].cpu().numpy(), hr_o, IBP_TOL[prec])
+    np.testing.assert_allclose(errs[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
+
+
+def test_full_frame_batch_c4_share():
+    """C4's single-GPU share: a batch of B = 4 full 3072 x 4096 frames (mono_cal_target's shape) in one call equals the frames
+    reconstructed one by one, bit for bit; noise-free frames of x keep x (fixed point)."""
+    S.set_precision("f32")
+    f, shifts, psf = 2, synth.NOMINAL_5, synth.gaussian_psf()
+    base = torch.from_numpy(synth.truth_image(384, 512, seed=15)).cuda().float().repeat(8, 8)
+    x = torch.stack([torch.roll(base, shifts=(37 * i, 91 * i), dims=(0, 1)) for i in range(4)]).contiguous()
+    lr = torch.stack([S.forward_model_batched(x, psf, s, f) for s in shifts], dim=1).contiguous()
+    assert lr.shape == (4, 5, 1536, 2048)
+    hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
+    assert S.last_path() == "mosaic"
+    assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    lrn = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255)
+    saa = S.shift_and_add_batched(lrn, shifts, f)
+    hr4, e4 = S.ibp_batched(lrn, shifts, psf, saa, f, 4, 0.5)
+    for i in (0, 3):
+        s1 = S.shift_and_add_batched(lrn[i:i + 1], shifts, f)
+        assert torch.equal(s1[0], saa[i])
+        h1, e1 = S.ibp_batched(lrn[i:i + 1], shifts, psf, s1, f, 4, 0.5)
+        assert torch.equal(h1[0], hr4[i]) and torch.equal(e1[0], e4[i])
