@@ -410,9 +410,10 @@ int srx_profile_get(int id, double *total_ms, long *launches)
     if (id < 0 || id >= KID_COUNT || !total_ms || !launches)
         return SRX_E_INVALID;
     Profiler &pf = profiler();
+    std::lock_guard<std::mutex> g(pf.mu);
     double tot = 0.0;
     long cnt = 0;
-    for (size_t i = 0; i < pf.n; i++) {
+    for (size_t i = 0; i < pf.rec.size(); i++) {
         if (pf.rec[i].id != id)
             continue;
         float ms = 0.f;

@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "srx.h"
 
 #define SRX_NPAD 12     // scipy.ndimage pre-pads 'nearest' inputs by 12 samples before the spline prefilter
@@ -89,30 +92,48 @@ struct ProfRecord {
     hipEvent_t a, b;
 };
 
+// Thread-safe: every method takes the mutex, a launch owns the record index begin() returned, and events are pooled (a
+// cleared log returns its events to the pool instead of destroying them, so a long profiled run creates each event once).
 struct Profiler {
-    bool on = false;
-    ProfRecord *rec = nullptr;
-    size_t n = 0, cap = 0;
-    void begin(int id, hipStream_t st)
+    std::mutex mu;
+    bool on = false;  // read without the lock by SRX_LAUNCH (a benign race: a launch is either timed or not)
+    std::vector<ProfRecord> rec;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t take()
     {
-        if (n == cap) {
-            cap = cap ? cap * 2 : 4096;
-            rec = (ProfRecord *)realloc(rec, cap * sizeof(ProfRecord));
+        hipEvent_t e = nullptr;
+        if (!pool.empty()) {
+            e = pool.back();
+            pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
         }
-        ProfRecord &r = rec[n];
-        r.id = id;
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, st);
+        return e;
     }
-    void end(hipStream_t st) { (void)hipEventRecord(rec[n++].b, st); }
+    long begin(int id, hipStream_t st)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        ProfRecord r{id, take(), take()};
+        if (!r.a || !r.b)
+            return -1;
+        (void)hipEventRecord(r.a, st);
+        rec.push_back(r);
+        return (long)rec.size() - 1;
+    }
+    void end(long i, hipStream_t st)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (i >= 0 && (size_t)i < rec.size())
+            (void)hipEventRecord(rec[(size_t)i].b, st);
+    }
     void clear()
     {
-        for (size_t i = 0; i < n; i++) {
-            (void)hipEventDestroy(rec[i].a);
-            (void)hipEventDestroy(rec[i].b);
+        std::lock_guard<std::mutex> g(mu);
+        for (const ProfRecord &r : rec) {
+            pool.push_back(r.a);
+            pool.push_back(r.b);
         }
-        n = 0;
+        rec.clear();
     }
 };
 
@@ -122,11 +143,10 @@ Profiler &profiler();
 #define SRX_LAUNCH(ID, KERNEL, GRID, BLOCK, SHMEM, ST, ...)                   \
     do {                                                                      \
         srx::Profiler &_pf = srx::profiler();                                 \
-        if (_pf.on)                                                           \
-            _pf.begin(ID, ST);                                                \
+        const long _pi = _pf.on ? _pf.begin(ID, ST) : -1;                     \
         hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, ST, __VA_ARGS__);      \
-        if (_pf.on)                                                           \
-            _pf.end(ST);                                                      \
+        if (_pi >= 0)                                                         \
+            _pf.end(_pi, ST);                                                 \
         if (hipGetLastError() != hipSuccess)                                  \
             return SRX_E_HIP;                                                 \
     } while (0)

@@ -195,6 +195,10 @@ def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, p
     f = int(factor)
     sh, shp = _host_f64(shifts_yx, (N, 2))
     k, kp = _host_f64(kernel)
+    if out is not None:  # the library writes B*H*W elements of the call's precision straight through this pointer
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.dtype != _TORCH_DT[prec] or tuple(out.shape) != (B, H, W)
+                or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous CUDA tensor of dtype {_TORCH_DT[prec]} and shape {(B, H, W)}")
     hr = torch.empty_like(h0) if out is None else out
     errors = torch.empty((B, int(n_iter)), dtype=torch.float64, device=x.device) if want_errors else None
     wt, wp, wn = _ws(_lib.load().srx_ibp_workspace_bytes(_ELEM[prec], B, N, h, w, H, W, f, flags))

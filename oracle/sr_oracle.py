@@ -164,9 +164,10 @@ def make_gaussian_psf(size=7, sigma=1.0):
 
 def interleave4(frames_u8):
     """numpy restatement of the vendor GUI's 4-frame interleave (opt_materials/software/XPR_Software.py:196-205,
-    388-410).  OpenCV is not installed in the build container, so this op is 'parity unpinned': it follows the
-    documented semantics of cv2.warpAffine for an integer translation (dst(x, y) = src(x - tx, y - ty)) with
-    BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba) and np.sum(..., dtype=np.uint8) (modulo 256)."""
+    388-410).  OpenCV is not installed in the build container, so this op is pinned by documented semantics, not by a
+    reference run: it follows cv2.warpAffine for an integer translation (dst(x, y) = src(x - tx, y - ty)) with
+    BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba) and np.sum(..., dtype=np.uint8) (modulo 256), and is checked against the
+    hand-derived known answer tests/golden/interleave4_3x3.npz (tools/make_interleave_fixture.py)."""
     fr = np.asarray(frames_u8, dtype=np.uint8)
     _, h, w = fr.shape
     H, W = 2 * h, 2 * w

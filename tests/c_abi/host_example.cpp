@@ -1,8 +1,10 @@
 // A plain C++ host of libsrx.so: HIP runtime + include/srx.h only (no Python, no torch) -- what a C / Go (cgo) / Java
-// (JNI) / Rust (FFI) caller of the drop-in boundary does.  Reconstructs one x2 item from N = 4 synthetic frames
-// (shift_and_add + 10 IBP iterations, nominal +-0.5 px shifts) in float32 and float64 on a non-default stream and
-// checks: both run, the MSE trace decreases, and the two precisions agree to float32 accuracy.
+// (JNI) / Rust (FFI) caller of the drop-in boundary does.  Reconstructs the C1 golden case (N = 4 frames at the reference's
+// nominal +-0.5 px shifts, 32x32 LR, x2: shift_and_add + 10 IBP iterations) in float32 and float64 on a non-default stream
+// and checks the HR image and the MSE trace against the REFERENCE's outputs for the same inputs (tests/golden/c_abi_c1.bin,
+// written by tools/make_c_abi_fixture.py from the golden vectors of the imported reference).
 //   hipcc -O2 -I include tests/c_abi/host_example.cpp -L <dir of libsrx.so> -lsrx -Wl,-rpath,<dir> -o host_example
+//   ./host_example tests/golden/c_abi_c1.bin
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -33,7 +35,7 @@ static int reconstruct(SAA saa_fn, IBP ibp_fn, const std::vector<double> &lr_hos
                        const double *shifts, const double *psf, std::vector<double> &hr_host, std::vector<double> &errs,
                        hipStream_t st)
 {
-    const int H = h * f, W = w * f, n_iter = 10;
+    const int H = h * f, W = w * f, n_iter = 10;  // the golden case's iteration count
     std::vector<T> tmp(lr_host.begin(), lr_host.end());
     T *lr = nullptr, *hr = nullptr;
     double *err = nullptr;
@@ -61,38 +63,70 @@ static int reconstruct(SAA saa_fn, IBP ibp_fn, const std::vector<double> &lr_hos
     return 0;
 }
 
-int main()
+// golden case written by tools/make_c_abi_fixture.py from tests/golden/synth_c1.npz (outputs of the imported reference)
+struct Golden {
+    int N, h, w, f, n_iter;
+    std::vector<double> shifts, psf, lr, saa, ibp, errors;
+};
+
+static bool read_golden(const char *path, Golden &g)
 {
-    const int N = 4, h = 48, w = 80, f = 2;
-    const double shifts[8] = {0.5, -0.5, 0.5, 0.5, -0.5, -0.5, -0.5, 0.5};  // (dy, dx) in LR pixels
-    double psf[49], sum = 0;
-    for (int i = 0; i < 7; i++)
-        for (int j = 0; j < 7; j++)
-            sum += psf[i * 7 + j] = std::exp(-((i - 3) * (i - 3) + (j - 3) * (j - 3)) / 2.0);
-    for (double &v : psf)
-        v /= sum;
-    std::vector<double> lr((size_t)N * h * w);
-    for (int k = 0; k < N; k++)  // smooth test pattern, a little different per frame, uint8-valued like the reference's inputs
-        for (int i = 0; i < h; i++)
-            for (int j = 0; j < w; j++)
-                lr[((size_t)k * h + i) * w + j] = std::floor(127.5 + 100.0 * std::sin(0.21 * i + 0.1 * k) * std::cos(0.17 * j - 0.05 * k));
+    std::FILE *fp = std::fopen(path, "rb");
+    if (!fp)
+        return false;
+    int hdr[5];
+    bool ok = std::fread(hdr, sizeof(int), 5, fp) == 5;
+    g.N = hdr[0], g.h = hdr[1], g.w = hdr[2], g.f = hdr[3], g.n_iter = hdr[4];
+    auto rd = [&](std::vector<double> &v, size_t n) {
+        v.resize(n);
+        ok = ok && std::fread(v.data(), sizeof(double), n, fp) == n;
+    };
+    if (ok) {
+        const size_t P = (size_t)g.h * g.f * g.w * g.f;
+        rd(g.shifts, 2 * (size_t)g.N), rd(g.psf, 49), rd(g.lr, (size_t)g.N * g.h * g.w), rd(g.saa, P), rd(g.ibp, P), rd(g.errors, (size_t)g.n_iter);
+    }
+    std::fclose(fp);
+    return ok;
+}
+
+static double max_abs_diff(const std::vector<double> &a, const std::vector<double> &b)
+{
+    double d = 0;
+    for (size_t i = 0; i < a.size(); i++)
+        d = std::fmax(d, std::fabs(a[i] - b[i]));
+    return d;
+}
+
+int main(int argc, char **argv)
+{
+    Golden g;
+    if (argc < 2 || !read_golden(argv[1], g) || g.n_iter != 10) {
+        std::printf("usage: host_example tests/golden/c_abi_c1.bin\n");
+        return 4;
+    }
+    const int N = g.N, h = g.h, w = g.w, f = g.f;
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
     std::vector<double> hr32, hr64, e32, e64;
-    int rc = reconstruct<float>(srx_saa_f32, srx_ibp_f32, lr, N, h, w, f, shifts, psf, hr32, e32, st);
+    int rc = reconstruct<float>(srx_saa_f32, srx_ibp_f32, g.lr, N, h, w, f, g.shifts.data(), g.psf.data(), hr32, e32, st);
     if (rc)
         return rc;
     std::printf("f32 path=%s  mse[0]=%.6f  mse[9]=%.6f\n", srx_last_path(), e32[0], e32[9]);
-    rc = reconstruct<double>(srx_saa_f64, srx_ibp_f64, lr, N, h, w, f, shifts, psf, hr64, e64, st);
+    rc = reconstruct<double>(srx_saa_f64, srx_ibp_f64, g.lr, N, h, w, f, g.shifts.data(), g.psf.data(), hr64, e64, st);
     if (rc)
         return rc;
     std::printf("f64 path=%s  mse[0]=%.6f  mse[9]=%.6f\n", srx_last_path(), e64[0], e64[9]);
-    double dmax = 0;
-    for (size_t i = 0; i < hr64.size(); i++)
-        dmax = std::fmax(dmax, std::fabs(hr32[i] - hr64[i]));
-    std::printf("max |f32 - f64| = %.3e DN over %zu HR pixels, version %d\n", dmax, hr64.size(), srx_version());
     HIP_OK(hipStreamDestroy(st));
-    if (!(e64[9] < e64[0]) || !(e32[9] < e32[0]) || !(dmax < 1e-2) || !(std::fabs(e32[9] - e64[9]) < 1e-4 * e64[9]))
+    // against the reference's own outputs for these inputs: SAA + 10 IBP iterations and the MSE trace
+    const double d64 = max_abs_diff(hr64, g.ibp), d32 = max_abs_diff(hr32, g.ibp);
+    double r64 = 0, r32 = 0;
+    for (int i = 0; i < g.n_iter; i++) {
+        r64 = std::fmax(r64, std::fabs(e64[i] / g.errors[i] - 1.0));
+        r32 = std::fmax(r32, std::fabs(e32[i] / g.errors[i] - 1.0));
+    }
+    std::printf("vs reference golden: max |f64 - ref| = %.3e DN (trace rel %.1e), max |f32 - ref| = %.3e DN (trace rel %.1e), %zu HR pixels, version %d\n",
+                d64, r64, d32, r32, hr64.size(), srx_version());
+    if (!(d64 < 1e-8) || !(r64 < 1e-10) || !(d32 < 1e-3) || !(r32 < 2e-5))
         return 1;
     std::printf("C ABI host example OK\n");
     return 0;

@@ -304,6 +304,8 @@ def test_interleave4_depth_to_space():
     """Vendor live-view interleave (XPR_Software.py:388-410): bit-exact vs the numpy restatement, and in the interior
     the pure PixelShuffle index map out[2i + py_k, 2j + px_k] = frame_k[i, j]."""
     from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "interleave4_3x3.npz"))  # hand-derived known answer (documented semantics)
+    assert np.array_equal(S.interleave4(g["frames"]), g["expected"])
     rng = np.random.default_rng(8)
     for (h, w) in [(5, 7), (32, 48), (1, 1)]:
         fr = rng.integers(0, 256, (4, h, w), dtype=np.uint8)

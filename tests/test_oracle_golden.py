@@ -145,3 +145,12 @@ def test_quantize_truncates():
 
 def test_psf_matches_reference(g_c1):
     close(O.make_gaussian_psf(), g_c1["psf_g"], 1e-17)
+
+
+def test_interleave4_known_answer():
+    """The vendor live view's 4-frame interleave (XPR_Software.py:196-205, 388-410): pinned by DOCUMENTED semantics, not by a
+    reference run (cv2 is absent here) -- tests/golden/interleave4_3x3.npz is written out by hand from the definition of
+    cv2.warpAffine for a pure translation and of BORDER_REFLECT_101 (tools/make_interleave_fixture.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interleave4_3x3.npz"))
+    assert np.array_equal(O.interleave4(g["frames"]), g["expected"])
