@@ -8,6 +8,7 @@
 #include "srx_fused.hpp"
 #include "srx_mosaic.hpp"
 #include "srx_patch.hpp"
+#include "srx_ztile.hpp"
 
 using namespace srx;
 
@@ -24,7 +25,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -312,7 +313,9 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
         if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
-            g_last_path = (!(flags & SRX_FLAG_TILES) && patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)) ? "patch" : "mosaic";
+            g_last_path = (!(flags & SRX_FLAG_TILES) && patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)) ? "patch"
+                          : ztile::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)                              ? "ztile"
+                                                                                                                    : "mosaic";
             return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
         }
         g_last_path = "fused";

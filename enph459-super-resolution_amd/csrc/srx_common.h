@@ -84,6 +84,7 @@ enum KernelId {
     KID_PREFILTER_SMALL,
     KID_PREFILTER_TILE,
     KID_IBP_PATCH,
+    KID_IBP_ZTILE,
     KID_COUNT
 };
 
@@ -207,10 +208,11 @@ __device__ unsigned long long srx_dbg_pstamps[24][4096];
 #define SRX_PSTAMP(PH)                                                                                         \
     do {                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {                                                      \
+        const unsigned _lb = blockIdx.x + gridDim.x * blockIdx.y;                                               \
+        if ((threadIdx.x & 63) == 0 && _lb < 256 && blockIdx.z == 0) {                                          \
             unsigned long long _t;                                                                               \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
-            srx_dbg_pstamps[PH][blockIdx.x * 16 + (threadIdx.x >> 6)] = _t;                                      \
+            srx_dbg_pstamps[PH][_lb * 16 + (threadIdx.x >> 6)] = _t;                                             \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)

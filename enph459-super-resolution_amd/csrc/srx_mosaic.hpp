@@ -33,6 +33,16 @@ struct AxisPlan;
 namespace patch {  // srx_patch.hpp: the patch-resident iteration (one workgroup per 256 x 256 HR patch)
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
 static inline size_t tabs_bytes(int B, int N);
+}  // namespace patch
+namespace ztile {  // srx_ztile.hpp: delta = 0 on CU-resident 256 x 256 tiles of a large frame, one launch per iteration
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline size_t tabs_bytes(int B, int N, int H, int W);
+static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st);
+}  // namespace ztile
+namespace patch {
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int n_iter, double step, double scale,
@@ -1030,7 +1040,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
            align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
            align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int)) +
            align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double)) +
-           (eb == 4 && H == 256 && W == 256 ? patch::tabs_bytes(B, N) : 0);  // srx_patch.hpp's tables
+           (eb == 4 && H == 256 && W == 256 ? patch::tabs_bytes(B, N) : 0) +  // srx_patch.hpp's tables
+           (eb == 4 && H >= 128 && W >= 128 ? ztile::tabs_bytes(B, N, H, W) : 0);  // srx_ztile.hpp's planes and tables
 }
 
 template <typename T>
@@ -1106,6 +1117,10 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
             return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
                                   errors, st);
         }
+        // integer HR shifts on a large frame: the whole iteration in one launch over CU-resident 256 x 256 tiles (srx_ztile.hpp)
+        if (ztile::eligible(4, N, H, W, sh, k, kh, kw, f))
+            return ztile::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale,
+                                  errors, st);
     }
     constexpr int TS = TileCfg<T>::T_HR;
     // timing ablations (results are wrong / an occupancy cap): compile-time only, -DSRX_ABLATE=<bits> -DSRX_ABLATE_LDS=<bytes>

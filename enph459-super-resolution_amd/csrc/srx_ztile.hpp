@@ -1,0 +1,539 @@
+// srx_ztile.hpp -- delta = 0 IBP iteration on CU-resident 256 x 256 tiles of a large frame, one launch per iteration.
+//
+// The reference's shipped defaults (all but rgb_cal_target) use nominal +-0.5 px shifts at f = 2: every HR shift is an integer
+// (delta = 0), the spline interpolation condition removes the prefilter, Y is the blurred image itself and the iteration of
+// mono_cal_target/run_sr.py:190-209 is   b = B hr;  G = M - C b (depth-to-space);  hr <- clip(hr + step * B'(G) / N)
+// (srx_mosaic.hpp).  The round-1 kernels ran that as two launches over 32 x 64 / 64 x 64 tiles with the G plane in HBM
+// (27 B per HR pixel against 13 algorithmic, 0.25 of the HBM roofline on a 3072 x 4096 frame).  Here one workgroup keeps a
+// 256 x 256 region in registers through the whole chain -- the machinery of srx_patch.hpp (64 x 64 blocks, column / row
+// layouts, wave-private LDS transposes, halo exchange through LDS) minus the recursions -- and writes the 244 x 244 pixels
+// whose 6-pixel dependency cone (3 for B, 3 for B') lies inside the region: 1.10x recompute, no intermediate plane.
+//
+// 512 threads = 8 waves, each owning 64 rows x 128 columns (two 64 x 64 blocks): with 256 registers per lane the 128-value
+// working plane, the 134-value blur window and the prefetched operands fit without spills (the 1024-thread / 128-register
+// layout of srx_patch.hpp spills ~150 values per iteration).
+//
+// Near band (LR row / column 0 replicated into SciPy's pad: pixels g < -n_min, in the first rows / columns of the IMAGE): tiles
+// on the top / left image edge evaluate the per-pixel lists of k_build_near from two LDS strips of b, as k_ibp_patch does.
+// The state ping-pongs between two buffers (a tile reads its neighbours' pixels of the previous iteration).
+#pragma once
+#include "srx_patch.hpp"
+#ifndef SRX_ZTILE_NSY
+#define SRX_ZTILE_NSY 1
+#endif
+
+namespace srx {
+namespace ztile {
+
+using patch::f8;
+using patch::sload8;
+using patch::TSD;
+
+constexpr int RG = 256;           // region width (and the stride of the strips)
+constexpr int HALO = 6;           // 3 (blur) + 3 (adjoint blur)
+constexpr int VT = RG - 2 * HALO; // 244 valid columns per tile
+constexpr int NSY = SRX_ZTILE_NSY;            // block rows per tile: region height 64 NSY.  Two (512 threads, 80 KB of LDS) lets TWO tiles share
+                                  // a CU, so one tile's memory phases overlap the other's arithmetic: a lone 256 x 256 tile per CU
+                                  // (NSY = 4) spends ~35 us of its ~90 us moving its own 0.9 MB through one CU's memory pipe
+constexpr int RGY = 64 * NSY, VTY = RGY - 2 * HALO;
+constexpr int SW = 4;             // strip pitch (rows of the top strip / columns of the left strip)
+// LDS: 16 wave regions of srx_patch.hpp (transpose image + exchange slots), then the near-band strips
+constexpr int OFF_YT = 4 * NSY * patch::RW, OFF_YL = OFF_YT + SW * RG, OFF_GT = OFF_YL + SW * RGY, OFF_GL = OFF_GT + SW * RG,
+              OFF_PART = OFF_GL + SW * RGY, LDS_WORDS = OFF_PART + 32;
+static_assert(LDS_WORDS * 4 <= (NSY == 1 ? 53 : NSY == 2 ? 80 : 160) * 1024, "LDS budget");
+
+struct ZArgs {
+    int H, W, tiles_x, tiles_y;
+    int HP, WP;              // padded state / operand planes: image at (6, 6), zero border, HP + 1 rows (the last is a trash row)
+    int exy, exx, nby, nbx;  // n_max (samples above the image), -n_min (near-band rows inside it), per axis
+    int Ey, Ex;              // padded Y index = rho + E (11)
+    int WT, LN, TOPN;        // near-band enumeration: top band [exy + nby][WT], then left band [H - nby][LN]
+    int ngrp;                // groups of 4 list entries per near-band pixel
+    float sn;                // step / N
+};
+
+struct ZTabs {
+    const float *Mt, *Ct;    // [B][WP][HP] / [WP][HP]: LR mosaic and count map, transposed (row layout: lane = row), zero-padded
+    const unsigned *CM;      // [B][WP / 2][HP]: both as 16 bits per pixel (C << 12 | M), two columns per word; valid where cmok[b]
+    const int *cmok;         // [B]: every M of the item is an integer < 4096 and every C < 16 (uint8 frames, at most 15 per pixel)
+    const patch::AxisW *aw;  // [2]: y, x (kb, kt un-scaled here: kq = 1)
+    const unsigned *nrec;    // [NT] cnt | cu << 8
+    const uint4 *nent;       // [ngrp][NT] four entries rho_y | rho_x << 16 (natural, clamped)
+    const float2 *Mn;        // [B][NT] (M, Mu)
+};
+
+static inline bool axis_ok(const mosaic::AxisPlan &pl, int N, int f)
+{
+    int nmin = pl.n[0], nmax = pl.n[0];
+    for (int k = 1; k < N; k++)
+        nmin = std::min(nmin, pl.n[k]), nmax = std::max(nmax, pl.n[k]);
+    // integer shifts; near band within the strips; no LR sample beyond the last image row (n_min >= -(f - 1))
+    return pl.zero && nmax >= 0 && nmax <= 1 && nmin <= 0 && -nmin <= SW - 1 && -nmin <= f - 1;
+}
+
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
+{
+    if (elem_bytes != 4 || H < 128 || W < 128 || f < 2 || (call_flags() & SRX_FLAG_TILES))
+        return false;
+    mosaic::AxisPlan py, px;
+    if (!mosaic::plan_axis(N, sh, 0, f, py) || !mosaic::plan_axis(N, sh, 1, f, px))
+        return false;
+    fused::Kernel7<float> kc;
+    fused::make_kernel7<float>(k, kh, kw, false, kc);
+    return kc.separable && axis_ok(py, N, f) && axis_ok(px, N, f);
+}
+
+// ---- once per call -----------------------------------------------------------------------------------------------------
+// Transposed, zero-padded far-field operands (padded coordinates = natural + 6, planes [WP][HP]):
+//   dst[px * HP + py] = src[(py - 6 + 13) * Wg + px - 6 + 13] inside the image, 0 in the border
+// so that the tile kernel needs no predicate: outside the image M = C = 0 gives G = 0, what the adjoint blur must see there.
+// grid (ceil(WP/32), ceil(HP/32), B + 1), block (32, 8).
+__global__ void __launch_bounds__(256)
+    k_ztile_prep(const float *__restrict__ Mg, const float *__restrict__ Cg, int B, int H, int W, int HP, int WP, int nby, int nbx,
+                 float *__restrict__ Mt, float *__restrict__ Ct)
+{
+    __shared__ float t[32][33];
+    const int Hg = H + 27, Wg = W + 27;
+    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const float *src = b < B ? Mg + (size_t)b * Hg * Wg : Cg;
+    float *dst = b < B ? Mt + (size_t)b * HP * WP : Ct;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int gy = y0 + r - HALO, gx = x0 + (int)threadIdx.x - HALO;
+        // near-band pixels (gy < nby or gx < nbx) come from the per-pixel lists in the kernel: zero here (their sums over several
+        // frames would not fit the 16-bit form)
+        t[r][threadIdx.x] = (gy >= nby && gy < H && gx >= nbx && gx < W) ? src[(size_t)(gy + 13) * Wg + gx + 13] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8)
+        if (x0 + r < WP && y0 + (int)threadIdx.x < HP)
+            dst[(size_t)(x0 + r) * HP + y0 + threadIdx.x] = t[threadIdx.x][r];
+}
+
+// (C << 12 | M) of two adjacent columns per word, when every value fits (uint8 sensor frames): 2 bytes per pixel instead of 8.
+// cmok[b] (preset non-zero) is cleared otherwise and the kernel reads the float planes.  grid (ceil(HP/256), WP/2, B)
+__global__ void __launch_bounds__(256)
+    k_ztile_pack(const float *__restrict__ Mt, const float *__restrict__ Ct, int HP, int WP, unsigned *__restrict__ CM, int *__restrict__ cmok)
+{
+    const int py = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
+    if (py >= HP)
+        return;
+    const size_t o0 = (size_t)(2 * k) * HP + py, o1 = o0 + HP;
+    const float m0 = Mt[(size_t)b * HP * WP + o0], m1 = Mt[(size_t)b * HP * WP + o1], c0 = Ct[o0], c1 = Ct[o1];
+    const bool ok = m0 == rintf(m0) && m1 == rintf(m1) && m0 >= 0.f && m1 >= 0.f && m0 < 4096.f && m1 < 4096.f && c0 < 16.f && c1 < 16.f;
+    CM[((size_t)b * (WP / 2) + k) * HP + py] = ((unsigned)c0 << 12 | (unsigned)m0) | ((unsigned)c1 << 12 | (unsigned)m1) << 16;
+    if (!ok)
+        atomicAnd(&cmok[b], 0);
+}
+
+// state planes: [B][HP + 1][WP], image at (6, 6).  copy-in (the border was zeroed by a memset) and copy-out.  grid (ceil(W/256), H, B)
+__global__ void __launch_bounds__(256) k_ztile_copy_in(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x < W)
+        dst[((size_t)b * (HP + 1) + y + HALO) * WP + x + HALO] = src[((size_t)b * H + y) * W + x];
+}
+__global__ void __launch_bounds__(256) k_ztile_copy_out(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x < W)
+        dst[((size_t)b * H + y) * W + x] = src[((size_t)b * (HP + 1) + y + HALO) * WP + x + HALO];
+}
+
+// near-band pixel T of the image enumeration -> natural coordinates
+__device__ __forceinline__ void near_coords(int T, const ZArgs &za, int &gy, int &gx)
+{
+    if (T < za.TOPN) {
+        const int r = T / za.WT;
+        gy = r - za.exy, gx = T - r * za.WT - za.exx;
+    } else {
+        const int q = T - za.TOPN, r = q / za.LN;
+        gy = za.nby + r, gx = q - r * za.LN - za.exx;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_ztile_near_tab(const int *__restrict__ ncu, const int *__restrict__ nyx, int NS, int PBy, int PBx, ZArgs za, int NT, unsigned *__restrict__ nrec,
+                     uint4 *__restrict__ nent)
+{
+    const int T = blockIdx.x * 256 + threadIdx.x;
+    if (T >= NT)
+        return;
+    int gy, gx;
+    near_coords(T, za, gy, gx);
+    const int ni = mosaic::near_index(gy + 13, gx + 13, za.W + 27, PBy, PBx), pk = ncu[ni], cnt = pk & 255, cu = pk >> 8;
+    nrec[T] = (unsigned)cnt | (unsigned)cu << 8;
+    for (int g = 0; g < NS / 4; g++) {
+        unsigned o[4];
+        for (int e = 0; e < 4; e++) {
+            const int c = nyx[(size_t)ni * NS + 4 * g + e];  // slots past cnt hold an in-range coordinate (k_build_near)
+            const int ry = min(max((c & 0xffff) - za.Ey, 0), za.H - 1), rx = min(max((c >> 16) - za.Ex, 0), za.W - 1);
+            o[e] = (unsigned)ry | (unsigned)rx << 16;
+        }
+        nent[(size_t)g * NT + T] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_ztile_near_m(const float *__restrict__ Mg, const float *__restrict__ Mu, int NB, int PBy, int PBx, ZArgs za, int NT, float2 *__restrict__ Mn)
+{
+    const int T = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (T >= NT)
+        return;
+    int gy, gx;
+    near_coords(T, za, gy, gx);
+    const int Wg = za.W + 27, Hg = za.H + 27, ni = mosaic::near_index(gy + 13, gx + 13, Wg, PBy, PBx);
+    Mn[(size_t)b * NT + T] = make_float2(Mg[((size_t)b * Hg + gy + 13) * Wg + gx + 13], Mu[(size_t)b * NB + ni]);
+}
+
+// MSE trace: sum of the tiles' partial sums of one iteration, fixed order.  grid B, block 256
+__global__ void __launch_bounds__(256)
+    k_ztile_trace(const double *__restrict__ epart, int ntiles, const double *__restrict__ Vtot, double scale, double *__restrict__ errors, int stride)
+{
+    __shared__ double part4[4];
+    const int b = blockIdx.x;
+    double *out = errors + (size_t)b * stride;
+    err_trace_reduce(epart, ntiles, b, Vtot[b], out, threadIdx.x, part4);  // tiles store unscaled sums
+    if (threadIdx.x == 0)
+        *out *= scale;
+}
+
+// =========================================================================================================================
+// One iteration on one tile.  grid (tiles_x, tiles_y, B), block 1024 = 16 waves: wave (s, u) owns the 64 x 64 block at region rows
+// 64 s, columns 64 u (the layout of k_ibp_patch: four waves per SIMD hide each other's LDS and memory waits; the first version,
+// 8 waves x 128 values in 256 registers, ran at two waves per SIMD and was slower than the two-kernel path it replaces).
+// State and operand planes are zero-padded (image at (6, 6)), so no load is predicated; a store of a pixel this tile does not
+// own (or outside the image) goes to the plane's trash row / out of the buffer's range.
+// =========================================================================================================================
+__global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
+    k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart)
+{
+    __shared__ float lds[LDS_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave >> 2, u = wave & 3;
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    const int H = za.H, W = za.W, HP = za.HP, WP = za.WP;
+    const int pr0 = ty * VTY, pc0 = tx * VT;  // padded coordinates of region (0, 0); natural = padded - 6
+    float *Rown = lds + wave * patch::RW;
+    const float *Rup = lds + (wave - 4) * patch::RW, *Rdn = lds + (wave + 4) * patch::RW;
+    const float *Rlf = lds + (wave - 1) * patch::RW, *Rrt = lds + (wave + 1) * patch::RW;
+    float *Yt = lds + OFF_YT, *Yl = lds + OFF_YL, *Gt = lds + OFF_GT, *Gl = lds + OFF_GL;
+    double *part = reinterpret_cast<double *>(lds + OFF_PART);
+    const float *awy = tb.aw[0].kb, *awx = tb.aw[1].kb;
+    const size_t splane = (size_t)(HP + 1) * WP, oplane = (size_t)HP * WP;
+    const __amdgpu_buffer_rsrc_t rs_src = fused::plane_rsrc(hr_src + (size_t)b * splane, splane);
+    const __amdgpu_buffer_rsrc_t rs_dst = fused::plane_rsrc(hr_dst + (size_t)b * splane, splane);
+    const bool top = ty == 0, left = tx == 0;  // block-uniform: tiles holding the near band
+
+    SRX_PSTAMP(0);
+    // ================= stage A: column layout.  a[i] = region (row 64 s + i, column 64 u + lane) =================
+    float a[64], r[64];
+    const int vc0 = (pc0 + 64 * u + lane) * 4, sr0 = (pr0 + 64 * s) * WP * 4;
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+        a[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+    // blur down the columns (three rows from the blocks above / below; zero at the region's edge: those outputs are outside
+    // every dependency cone that ends in a stored pixel)
+    SRX_PSTAMP(1);
+    auto vblur = [&](const f8 k) { patch::blur_block(a, s == 0, s == NSY - 1, Rown, Rup, Rdn, patch::SLOT0, lane, k); };
+    vblur(sload8(awy));
+    SRX_PSTAMP(2);
+    __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
+    SRX_PSTAMP(3);
+    patch::transpose64(a, r, Rown, lane);
+    SRX_PSTAMP(4);
+    // ================= stage B: row layout.  r[j] = region (row 64 s + lane, column 64 u + j) =================
+    const int rr = 64 * s + lane, gy = pr0 + rr - HALO;  // this lane's region / image row
+    const bool rowin = gy >= 0 && gy < H, rowown = rr >= HALO && rr < RGY - HALO;
+    const int gx0 = pc0 - HALO;                        // image column of region column 0
+    // the operands of the G step, 16 bits per pixel (16 columns = 8 words per batch, one batch ahead of its use: the first is
+    // in flight during the row blur)
+    const int cmok = __builtin_amdgcn_readfirstlane(tb.cmok[b]);
+    const size_t cplane = (size_t)(WP / 2) * HP;
+    const __amdgpu_buffer_rsrc_t rsP = fused::plane_rsrc(tb.CM + (size_t)b * cplane, cplane);
+    const int sp0 = ((pc0 + 64 * u) / 2) * HP * 4, vp = (pr0 + rr) * 4;
+    unsigned cma[8], cmb[8];
+    if (cmok) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            cma[k] = __builtin_amdgcn_raw_buffer_load_b32(rsP, vp, sp0 + k * HP * 4, 0);
+    }
+    patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, sload8(awx));
+    SRX_PSTAMP(5);
+    float sq = 0.f;
+    // ---- near band (tiles on the top / left image edge): strips of b, the listed sums, strips of G
+    if (top || left) {
+        if (top && gy >= 0 && gy <= za.nby) {
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                Yt[gy * RG + 64 * u + j] = r[j];
+        }
+        if (left && u == 0) {
+#pragma unroll
+            for (int j = 0; j < SW; j++)
+                if (j <= za.nbx)
+                    Yl[rr * SW + j] = r[HALO + j];
+        }
+        __syncthreads();
+        const int ntop = top ? (za.exy + za.nby) * RG : 0, nleft = left ? RGY * za.LN : 0;
+        const int NT = za.TOPN + (H - za.nby) * za.LN;
+        for (int t = tid; t < ntop + nleft; t += 256 * NSY) {
+            int ngy, ngx;
+            float *dst;
+            if (t < ntop) {
+                const int rw = t / RG, cc = t - rw * RG;
+                ngy = rw - za.exy, ngx = gx0 + cc;
+                dst = Gt + rw * RG + cc;
+            } else {
+                const int q = t - ntop, rw = q / za.LN, cc = q - rw * za.LN;
+                ngy = pr0 - HALO + rw, ngx = cc - za.exx;
+                dst = Gl + rw * SW + cc;
+                if (ngy < za.nby)  // the first rows belong to the top band
+                    continue;
+            }
+            if (ngx < -za.exx || ngx >= W || ngy >= H) {
+                *dst = 0.f;
+                continue;
+            }
+            const int T = ngy < za.nby ? (ngy + za.exy) * za.WT + ngx + za.exx : za.TOPN + (ngy - za.nby) * za.LN + ngx + za.exx;
+            const unsigned rec = tb.nrec[T];
+            const int cnt = rec & 255, cu = rec >> 8;
+            const float2 nm = tb.Mn[(size_t)b * NT + T];
+            auto Yat = [&](int ry, int rx) -> float {  // natural, clamped coordinates -> the strip holding them
+                return ngy < za.nby ? Yt[ry * RG + rx - gx0] : Yl[(ry - (pr0 - HALO)) * SW + rx];
+            };
+            float ys = 0.f;
+            for (int g = 0; 4 * g < cnt; g++) {
+                const uint4 e = tb.nent[(size_t)g * NT + T];
+                const int c = cnt - 4 * g;
+                ys += Yat(e.x & 0xffff, e.x >> 16) + (c > 1 ? Yat(e.y & 0xffff, e.y >> 16) : 0.f) + (c > 2 ? Yat(e.z & 0xffff, e.z >> 16) : 0.f) +
+                      (c > 3 ? Yat(e.w & 0xffff, e.w >> 16) : 0.f);
+            }
+            *dst = (ngx >= 0 && ngy >= 0) ? nm.x - ys : 0.f;  // samples above / left of the image count for the MSE trace only
+            // the counted samples' share of the MSE trace, once per pixel: by the tile that owns its (clamped) position
+            const int cy = min(max(ngy, 0), H - 1), cx = min(max(ngx, 0), W - 1);
+            if (cu > 0 && cy / VTY == ty && cx / VT == tx) {
+                const float gu = nm.y - (float)cu * Yat(cy, cx);
+                sq += gu * gu / (float)cu;
+            }
+        }
+        __syncthreads();
+    }
+    SRX_PSTAMP(6);
+    // ---- G = M - C b.  Outside the image the padded operands are zero: G = 0 there, what the adjoint blur must see
+    {
+        const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(tb.Mt + (size_t)b * oplane, oplane);
+        const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(tb.Ct, oplane);
+        const int sc0 = (pc0 + 64 * u) * HP * 4;
+        float sqf = 0.f;
+        // far-field pixels this tile owns: region columns 6 .. 249 without the near-band columns of the image's left edge.  The
+        // few columns concerned (j < 9 of u = 0, j >= 58 of u = 3) get a wave-uniform 0 / 1 weight.
+        const int jlo = u == 0 ? HALO + (left ? za.nbx : 0) : 0, jhi = u == 3 ? 58 : 64;
+        // one body, two sources of (M, C): the 16-bit words, or the float planes (frames that are not uint8)
+        auto gstep = [&](auto fetch) {
+#pragma unroll
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                float mv[8], cv[8];
+                fetch(j0, mv, cv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float g = fmaf(-cv[j], r[j0 + j], mv[j]);
+                    float g2 = g * g * mosaic::rcp_count(cv[j]);
+                    if (j0 + j < 9)
+                        g2 = j0 + j >= jlo ? g2 : 0.f;
+                    if (j0 + j >= 58)
+                        g2 = j0 + j < jhi ? g2 : 0.f;
+                    sqf += g2;
+                    r[j0 + j] = g;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (cmok) {
+            gstep([&](int j0, float(&mv)[8], float(&cv)[8]) {
+                // words of 2 columns; cma / cmb hold 16 columns each, alternately: refill the idle one at every second batch.
+                // (All 32 words at once, issued before the row blur, was slower: 87 vs 66 us per iteration on a 3072 x 4096 frame.)
+                unsigned(&cur)[8] = (j0 & 16) ? cmb : cma;
+                unsigned(&nxt)[8] = (j0 & 16) ? cma : cmb;
+                if ((j0 & 8) == 0 && j0 + 16 < 64) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        nxt[k] = __builtin_amdgcn_raw_buffer_load_b32(rsP, vp, sp0 + ((j0 + 16) / 2 + k) * HP * 4, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int jj = (j0 & 8) + j;
+                    const unsigned v = (jj & 1) ? cur[jj >> 1] >> 16 : cur[jj >> 1] & 0xffffu;
+                    mv[j] = (float)(v & 0xfffu), cv[j] = (float)(v >> 12);
+                }
+            });
+        } else {
+            gstep([&](int j0, float(&mv)[8], float(&cv)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    mv[j] = fused::buf_load<float>(rsM, vp, sc0 + (j0 + j) * HP * 4);
+                    cv[j] = fused::buf_load<float>(rsC, vp, sc0 + (j0 + j) * HP * 4);
+                }
+            });
+        }
+        sq += (rowown && rowin && gy >= za.nby) ? sqf : 0.f;
+        if (top && gy >= 0 && gy < za.nby) {
+            const float *src = Gt + (gy + za.exy) * RG + 64 * u;  // zero outside the image (the near-band loop wrote every pixel)
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                r[j] = src[j];
+        } else if (left && u == 0 && rowin) {
+            const float *src = Gl + rr * SW + za.exx;
+#pragma unroll
+            for (int j = 0; j < SW - 1; j++)
+                if (j < za.nbx)
+                    r[HALO + j] = src[j];
+        }
+    }
+    SRX_PSTAMP(7);
+    // ---- MSE partial of this tile (summed in a fixed order by thread 0 behind the next barrier)
+    if (epart) {
+        const double ws = wave_sum((double)sq);
+        if (lane == 0)
+            part[wave] = ws;
+    }
+    patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, sload8(awx + 8));
+    if (epart && tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4 * NSY; i++)
+            t += part[i];
+        epart[((size_t)b * za.tiles_y + ty) * za.tiles_x + tx] = t;
+    }
+    SRX_PSTAMP(8);
+    __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
+    patch::transpose64(r, a, Rown, lane);
+    SRX_PSTAMP(9);
+    // ================= stage C: column layout again =================
+    vblur(sload8(awy + 8));
+    SRX_PSTAMP(10);
+    // ---- update and store.  Rows this tile does not own (or below the image) go to the trash row; columns it does not own
+    // (or right of the image) get an offset beyond the buffer's range, which drops the store.
+    const int trash = HP * WP * 4;
+    const int cc = 64 * u + lane;
+    const int vst = (cc >= HALO && cc < RG - HALO && pc0 + cc - HALO < W) ? vc0 : 0x7ffffff0;
+    // loads and arithmetic first, every store at the very end: vmcnt counts loads and stores in one order, so a wait for a batch of
+    // loads behind a batch of stores would also wait for those stores to complete
+    {
+        float hv[16], hw[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            hv[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float(&cur)[16] = (q & 1) ? hw : hv;
+            float(&nxt)[16] = (q & 1) ? hv : hw;
+            if (q < 3) {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    nxt[i] = fused::buf_load<float>(rs_src, vc0, sr0 + (16 * (q + 1) + i) * WP * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                a[16 * q + i] = __builtin_amdgcn_fmed3f(fmaf(a[16 * q + i], za.sn, cur[i]), 0.f, 255.f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    SRX_PSTAMP(11);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const int rw = 64 * s + i;  // wave-uniform
+        const bool rok = rw >= HALO && rw < RGY - HALO && pr0 + rw - HALO < H;
+        fused::buf_store<float>(a[i], rs_dst, vst, rok ? sr0 + i * WP * 4 : trash);
+    }
+    SRX_PSTAMP(12);
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+static inline size_t tabs_bytes(int B, int N, int H, int W)
+{
+    const size_t ngrp = ((size_t)N + 3) / 4, NT = (size_t)6 * (W + 4) + (size_t)H * 6;
+    const size_t ty = cdiv(H, VTY), tx = cdiv(W, VT), HP = ty * VTY + 2 * HALO, WP = tx * VT + 2 * HALO;
+    return align_up((size_t)B * HP * WP * 4) + 2 * align_up((size_t)B * (HP + 1) * WP * 4) + align_up(HP * WP * 4) +
+           align_up((size_t)B * (WP / 2) * HP * 4) + align_up((size_t)B * 4) +
+           align_up(2 * sizeof(patch::AxisW)) + align_up(NT * 4) + align_up(ngrp * NT * 16) + align_up((size_t)B * NT * 8) +
+           2 * align_up((size_t)B * ty * tx * 8);
+}
+
+static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st)
+{
+    ZArgs za;
+    za.H = H, za.W = W, za.tiles_x = cdiv(W, VT), za.tiles_y = cdiv(H, VTY);
+    za.HP = za.tiles_y * VTY + 2 * HALO, za.WP = za.tiles_x * VT + 2 * HALO;
+    const int HP = za.HP, WP = za.WP;
+    auto ext = [&](const mosaic::AxisPlan &pl, int &ex, int &nb) {
+        int nmin = pl.n[0], nmax = pl.n[0];
+        for (int k = 1; k < N; k++)
+            nmin = std::min(nmin, pl.n[k]), nmax = std::max(nmax, pl.n[k]);
+        ex = nmax, nb = -nmin;
+    };
+    ext(py, za.exy, za.nby);
+    ext(px, za.exx, za.nbx);
+    za.Ey = py.E, za.Ex = px.E;
+    za.WT = W + za.exx, za.LN = za.exx + za.nbx, za.TOPN = (za.exy + za.nby) * za.WT;
+    za.ngrp = NS / 4;
+    za.sn = (float)step / (float)N;
+    const int NT = za.TOPN + (H - za.nby) * za.LN, ntiles = za.tiles_x * za.tiles_y;
+    const size_t splane = (size_t)(HP + 1) * WP;
+    float *Mt = ar.take<float>((size_t)B * HP * WP), *s0 = ar.take<float>(B * splane), *s1 = ar.take<float>(B * splane),
+          *Ct = ar.take<float>((size_t)HP * WP);
+    unsigned *CM = ar.take<unsigned>((size_t)B * (WP / 2) * HP);
+    int *cmok = ar.take<int>(B);
+    patch::AxisW *aw = ar.take<patch::AxisW>(2);
+    unsigned *nrec = ar.take<unsigned>(NT);
+    uint4 *nent = ar.take<uint4>((size_t)za.ngrp * NT);
+    float2 *Mn = ar.take<float2>((size_t)B * NT);
+    double *ep0 = ar.take<double>((size_t)B * ntiles), *ep1 = ar.take<double>((size_t)B * ntiles);
+    if (!ar.ok)
+        return SRX_E_WORKSPACE;
+    patch::AxisWPair awp;
+    for (int i = 0; i < 8; i++) {
+        awp.y.kb[i] = i < 7 ? kc.cy[i] : 0.f, awp.y.kt[i] = i < 7 ? kt.cy[i] : 0.f, awp.y.wfb[i] = 0.f;
+        awp.x.kb[i] = i < 7 ? kc.cx[i] : 0.f, awp.x.kt[i] = i < 7 ? kt.cx[i] : 0.f, awp.x.wfb[i] = 0.f;
+    }
+    hipLaunchKernelGGL(patch::k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
+    SRX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ztile_prep, dim3(cdiv(WP, 32), cdiv(HP, 32), B + 1), dim3(32, 8), 0, st, Mg, Cg, B, H, W, HP, WP, za.nby, za.nbx, Mt, Ct);
+    SRX_CHECK_LAUNCH();
+    if (hipMemsetAsync(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+        return SRX_E_HIP;
+    hipLaunchKernelGGL(k_ztile_pack, dim3(cdiv(HP, 256), WP / 2, B), dim3(256), 0, st, Mt, Ct, HP, WP, CM, cmok);
+    SRX_CHECK_LAUNCH();
+    // padded state planes: zero borders (and trash rows) once, then the image
+    if (hipMemsetAsync(s0, 0, B * splane * sizeof(float), st) != hipSuccess || hipMemsetAsync(s1, 0, B * splane * sizeof(float), st) != hipSuccess)
+        return SRX_E_HIP;
+    hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0);
+    SRX_CHECK_LAUNCH();
+    if (NT > 0) {
+        hipLaunchKernelGGL(k_ztile_near_tab, dim3(cdiv(NT, 256)), dim3(256), 0, st, ncu, nyx, NS, py.PB, px.PB, za, NT, nrec, nent);
+        SRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_ztile_near_m, dim3(cdiv(NT, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, za, NT, Mn);
+        SRX_CHECK_LAUNCH();
+    }
+    ZTabs tb{Mt, Ct, CM, cmok, aw, nrec, nent, Mn};
+    // ping-pong between the two padded planes (a tile reads its neighbours' pixels of the previous iteration)
+    const dim3 grid(za.tiles_x, za.tiles_y, B);
+    for (int it = 0; it < n_iter; it++) {
+        const float *src = (it & 1) ? s1 : s0;
+        float *dst = (it & 1) ? s0 : s1;
+        double *ep = errors ? ((it & 1) ? ep1 : ep0) : nullptr;
+        SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep);
+        if (errors) {
+            hipLaunchKernelGGL(k_ztile_trace, dim3(B), dim3(256), 0, st, ep, ntiles, Vtot, scale, errors + it, n_iter);
+            SRX_CHECK_LAUNCH();
+        }
+    }
+    hipLaunchKernelGGL(k_ztile_copy_out, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, (n_iter & 1) ? s1 : s0, H, W, HP, WP, hr);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+}  // namespace ztile
+}  // namespace srx

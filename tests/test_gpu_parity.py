@@ -225,7 +225,8 @@ FUSED_CFGS = {
     # name: (factor, shifts (LR px), psf, (h, w), expected path)
     "f2_meas": (2, synth.MEASURED_4, "asym", (150, 277), "fused"),          # distinct sub-pixel fractions: per-frame tiles
     "f3_k5": (3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], "asym5", (60, 75), "fused"),
-    "f2_nom5": (2, synth.NOMINAL_5, "gauss", (131, 200), "mosaic"),         # integer HR shifts: pure depth-to-space
+    "f2_nom5": (2, synth.NOMINAL_5, "gauss", (131, 200), "mosaic", "ztile"),  # integer HR shifts: pure depth-to-space; IBP on CU-resident tiles
+    "f2_nom4_big": (2, synth.NOMINAL_4, "gauss", (150, 277), "mosaic", "ztile"),  # several 244-pixel tiles per axis, ragged last tiles
     "f4_nom4": (4, synth.NOMINAL_4, "asym", (70, 90), "mosaic"),
     "f4_ph16": (4, synth.phase_shifts(4), "gauss", (70, 90), "mosaic"),     # the bench workload: all fractions 0.5
     "f3_ph9": (3, synth.phase_shifts(3), "asym", (50, 66), "mosaic"),       # fractions 0 (3 phases centred on 0)
@@ -242,7 +243,8 @@ def test_fused_path_vs_oracle(prec, cfg):
     from oracle import sr_oracle as O
     O.set_threads(8)
     try:
-        f, shifts, psf_name, (h, w), want = FUSED_CFGS[cfg]
+        f, shifts, psf_name, (h, w), want = FUSED_CFGS[cfg][:5]
+        want_ibp = FUSED_CFGS[cfg][5] if len(FUSED_CFGS[cfg]) > 5 else want
         psf = {"asym": synth.asymmetric_psf(), "gauss": synth.gaussian_psf(),
                "asym5": synth.asymmetric_psf()[1:6, 1:6] / synth.asymmetric_psf()[1:6, 1:6].sum()}[psf_name]
         truth = synth.truth_image(h * f, w * f, seed=77)
@@ -258,9 +260,14 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "fused"
     close(saa_p[0].cpu().numpy(), saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
-    assert S.last_path() == want
+    assert S.last_path() == (want_ibp if prec == "f32" else want)
     close(hr, hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
+    if want_ibp != want and prec == "f32":  # the tile kernels of srx_mosaic.hpp on the same input
+        hr_t, errs_t = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_TILES)
+        assert S.last_path() == want
+        close(hr_t[0].cpu().numpy(), hr_o, IBP_TOL[prec])
+        np.testing.assert_allclose(errs_t[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
     # the composed (literal) and the per-frame fused HIP paths agree with it
     hr_c, errs_c = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_COMPOSED)
     assert S.last_path() == "composed"
@@ -400,22 +407,23 @@ def test_full_size_linearity():
 
 def test_full_frame_paths_agree_and_trace_is_deterministic():
     """The reference's own full-frame shapes, noisy frames, one item.  mono_cal_target (N = 5 nominal, f = 2, 3072x4096:
-    the delta = 0 mosaic kernels, 6370 forward tiles) against the per-frame fused path; rgb_cal_target (N = 4 measured
-    shifts, 1536x2048: per-frame fused) against the composed path.  The MSE trace is a fixed-order sum of per-wave partial
-    sums (no atomics): two runs are bit-identical."""
+    the delta = 0 kernel on CU-resident tiles, then the two-launch mosaic tile kernels) against the per-frame fused path;
+    rgb_cal_target (N = 4 measured shifts, 1536x2048: per-frame fused) against the composed path.  The MSE trace is a
+    fixed-order sum of partial sums (no atomics): two runs are bit-identical."""
     S.set_precision("f32")
     gen = torch.Generator(device="cuda")
     gen.manual_seed(11)
-    for f, shifts, psf, tile, reps, want, other in (
-            (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "mosaic", S.FLAG_PER_FRAME),
-            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "fused", S.FLAG_COMPOSED)):
+    for f, shifts, psf, tile, reps, want, main, other in (
+            (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "ztile", S.FLAG_AUTO, S.FLAG_PER_FRAME),
+            (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "mosaic", S.FLAG_TILES, S.FLAG_PER_FRAME),
+            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "fused", S.FLAG_AUTO, S.FLAG_COMPOSED)):
         big = torch.from_numpy(synth.truth_image(*tile, seed=6)).cuda().float().repeat(*reps)[None].contiguous()
         lr = torch.stack([S.forward_model_batched(big, psf, s, f) for s in shifts], dim=1)
         lr = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255).contiguous()
         saa = S.shift_and_add_batched(lr, shifts, f)
-        hr_a, e_a = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5)
+        hr_a, e_a = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5, flags=main)
         assert S.last_path() == want
-        hr_b, e_b = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5)
+        hr_b, e_b = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5, flags=main)
         assert torch.equal(hr_a, hr_b) and torch.equal(e_a, e_b)
         hr_o, e_o = S.ibp_batched(lr, shifts, psf, saa, f, 4, 0.5, flags=other)
         assert S.last_path() != want
@@ -472,9 +480,9 @@ def test_delta_zero_fused_forward_matches_two_kernel_form(prec):
     lr = torch.round(torch.rand((3, 5, 75, 131), generator=gen, device="cuda", dtype=dt) * 255)
     init = S.shift_and_add_batched(lr, synth.NOMINAL_5, 2)
     for psf in (synth.gaussian_psf(), synth.asymmetric_psf()):
-        hr_a, e_a = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5)
+        hr_a, e_a = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5, flags=S.FLAG_TILES)
         assert S.last_path() == "mosaic"
-        hr_b, e_b = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5, flags=S.FLAG_DIAG_NO_ZERO_FUSE)
+        hr_b, e_b = S.ibp_batched(lr, synth.NOMINAL_5, psf, init, 2, 5, 0.5, flags=S.FLAG_TILES | S.FLAG_DIAG_NO_ZERO_FUSE)
         assert S.last_path() == "mosaic"
         assert float((hr_a - hr_b).abs().max()) <= (1e-10 if prec == "f64" else 2e-4)
         np.testing.assert_allclose(e_a.cpu().numpy(), e_b.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)
@@ -596,7 +604,7 @@ def test_full_frame_batch_c4_share():
     lr = torch.stack([S.forward_model_batched(x, psf, s, f) for s in shifts], dim=1).contiguous()
     assert lr.shape == (4, 5, 1536, 2048)
     hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
-    assert S.last_path() == "mosaic"
+    assert S.last_path() == "ztile"
     assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Phase stamps of k_ibp_ztile (diagnostic build, -DSRX_STAMPS): one 3072x4096 frame, lane 0 of every wave of the first 256 tiles."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enph459-super-resolution_amd"))
+import torch
+import sr_mi355x as S
+from sr_mi355x import _lib, synth
+B = int(os.environ.get("STAMPS_B", "1"))
+lr = torch.round(torch.rand((B, 5, 1536, 2048), device="cuda") * 255)
+saa = S.shift_and_add_batched(lr, synth.NOMINAL_5, 2)
+S.ibp_batched(lr, synth.NOMINAL_5, synth.gaussian_psf(), saa, 2, 3, 0.5)
+print("path", S.last_path())
+buf = np.zeros((24, 4096), dtype=np.uint64)
+lib = _lib.load(); lib.srx_debug_pstamps.argtypes = [ctypes.c_void_p]
+assert lib.srx_debug_pstamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+NPH = 13
+t = buf[:NPH].astype(np.int64).reshape(NPH, 256, 16)[:, :, :4]
+names = ["load 64 rows", "blur_v", "barrier", "transpose 1", "prefetch + blur_h", "near band (edge tiles)", "G step", "MSE + blur'_h", "barrier + transpose 2", "blur'_v", "update (loads)", "stores"]
+ok = t[0, :, 0] > 0
+t = t[:, ok]
+tot = t[NPH - 1] - t[0]
+print(f"{ok.sum()} tiles x 4 waves; cycles first -> last stamp: median {np.median(tot):.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f}")
+for i in range(NPH - 1):
+    d = t[i + 1] - t[i]
+    print(f"  {names[i]:26s} median {np.median(d):8.0f}  mean {d.mean():8.0f}  max {d.max():8d}  share {100 * d.mean() / tot.mean():5.1f} %")
