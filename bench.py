@@ -89,6 +89,43 @@ def workload(synth, name, batch, iters):
     raise ValueError(name)
 
 
+def session_e2e(S, synth, n_sessions=2, reps=4, lr_hw=(768, 1024)):
+    """sr_mi355x.session.process_sessions on synthetic barcode sessions written as PNG files (the reference's mono_barcodes layout,
+    mono_barcodes/run_sr.py:89-130,293-351: corner{c}_rep{rr}.png, 4 corners, nominal +-0.5 px, 80 iterations per rep): decode,
+    upload, Native-2x + SAA + IBP for all reps of a session in one batched call, quantise, encode, with the host work of session k + 1
+    overlapped with the device work of session k.  Wall time per rep and HR-MP/s, file to file."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from sr_mi355x import session
+    h, w = lr_hw
+    tmp = tempfile.mkdtemp(prefix="srx_e2e_")
+    try:
+        rng = np.random.default_rng(3)
+        base = synth.truth_image(h, w, seed=77)
+        for k in range(n_sessions):
+            d = os.path.join(tmp, "data", f"sheet{k}")
+            os.makedirs(d)
+            for r in range(reps):
+                for c in range(4):
+                    fr = np.clip(np.roll(base, (c + r, 2 * c + k), axis=(0, 1)) + rng.normal(0, 1, base.shape), 0, 255).astype(np.uint8)
+                    Image.fromarray(fr).save(os.path.join(d, f"corner{c}_rep{r:02d}.png"))
+        psf = S.make_gaussian_psf()
+        sessions = session.discover_sessions(os.path.join(tmp, "data"), "mono_barcodes")
+        session.process_sessions(sessions[:1], psf, os.path.join(tmp, "warm"), "mono_barcodes", verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        written = session.process_sessions(sessions, psf, os.path.join(tmp, "out"), "mono_barcodes", verbose=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = len(written)
+        return {"workload": f"{n_sessions} mono_barcodes sessions x {reps} reps, {h}x{w} uint8 PNG frames -> {2 * h}x{2 * w}, 80 IBP iterations, PNG in -> 4 PNGs out per rep",
+                "reps_reconstructed": n, "wall_s": round(dt, 3), "ms_per_rep": round(dt / n * 1e3, 2),
+                "value": round(n * 4 * h * w / 1e6 / dt, 2), "unit": "HR-MP/s (files to files)", "path": S.last_path()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, allmax=None, profile=True, world=1):
     """warmup + `steps` timed reconstructions (SAA + IBP) of one workload, inputs resident in HBM; then one extra, untimed step
     with HIP events around every fused-path launch for the iteration-level roofline:
@@ -284,6 +321,10 @@ def main():
             del r
             torch.cuda.empty_cache()
         S.set_precision(prec)
+
+    # ---- the real-data driver end to end: PNG files in, PNG files out (mono_barcodes layout, synthetic frames) ----
+    if legs is not None:
+        legs["session_e2e"] = session_e2e(S, synth)
 
     # ---- secondary figures: shift_and_add alone, and the same step from / to HOST buffers ----
     extras = None

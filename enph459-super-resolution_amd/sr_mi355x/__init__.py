@@ -8,7 +8,7 @@ import importlib
 
 _API = ("blur", "forward_model", "back_project", "shift_and_add", "ibp", "ndi_zoom", "ndi_shift",
         "blur_batched", "shift_batched", "zoom_batched", "forward_model_batched", "back_project_batched",
-        "shift_and_add_batched", "ibp_batched", "decimate", "extract_red", "zero_insert", "mean_frames",
+        "shift_and_add_batched", "ibp_batched", "decimate", "extract_red", "zero_insert", "mean_frames", "mean_frames_batched",
         "quantize_u8", "u8_to_float", "interleave4", "make_gaussian_psf", "set_precision", "get_precision", "last_path",
         "FLAG_AUTO", "FLAG_COMPOSED", "FLAG_FUSED", "FLAG_PER_FRAME", "FLAG_TILES", "FLAG_DIAG_NO_ZERO_FUSE",
         "FLAG_DIAG_NO_SEPARABLE", "FLAG_DIAG_NO_PREFILTER_TILE", "FLAG_DIAG_V1")

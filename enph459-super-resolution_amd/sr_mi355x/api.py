@@ -298,6 +298,16 @@ def mean_frames(stack):
     return _out(out, was_np)
 
 
+def mean_frames_batched(stacks):
+    """[B, R, ...] -> [B, ...]: np.mean(axis=0) of every item's stack in one call."""
+    x, was_np = _to_dev(stacks, _PRECISION)
+    B, R = x.shape[0], x.shape[1]
+    n = x[0, 0].numel()
+    out = torch.empty((B,) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    _lib.check(_fn("srx_mean_frames", _PRECISION)(_p(x), B, R, n, _p(out), _stream()), "srx_mean_frames")
+    return _out(out, was_np)
+
+
 def quantize_u8(img):
     """np.clip(img, 0, 255).astype(np.uint8): clamp, then truncate (run_sr.py:303)."""
     x, was_np = _to_dev(img, _PRECISION)

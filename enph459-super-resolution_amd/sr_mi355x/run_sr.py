@@ -3,6 +3,12 @@
 Same four flags as the reference's drivers (mono_cal_target/run_sr.py:320-331: --psf {gaussian,measured},
 --psf-dir, --data-dir, --output-dir) plus --kind, because the reference has one script per experiment layout
 while this is one entry point, and --precision.
+
+Several GPUs: launch it under torchrun, one process per GPU --
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m sr_mi355x.run_sr --kind ... --data-dir ...
+Session i goes to rank i mod G (the reference's outer loop order, mono_cal_target/run_sr.py:358-360); the ranks share nothing
+but the output directory, so there is no collective on the data path, only a barrier before rank 0 reports the total time.
+RANK / LOCAL_RANK / WORLD_SIZE are read, and the device chosen, BEFORE the first GPU call.
 """
 import argparse
 import os
@@ -24,6 +30,14 @@ def main(argv=None):
                     help="mono_cal_target only: also write metrics.json (slanted-edge MTF50/MTF10, bar contrast: the "
                          "summary of the reference's analysis.ipynb) next to the PNGs")
     args = ap.parse_args(argv)
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:  # one process per GPU: pick the device before anything touches it
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0 if os.environ.get("SRX_ONE_GPU") else local_rank)  # SRX_ONE_GPU: rehearsal of the N > 1 path on a one-GPU box
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")  # a barrier and nothing else: the data path has no collective
     api.set_precision(args.precision)
     if args.psf == "measured":
         if not args.psf_dir:
@@ -36,13 +50,14 @@ def main(argv=None):
     sessions = session.discover_sessions(args.data_dir, args.kind)
     print(f"Found {len(sessions)} session(s):\n" + "\n".join(f"  {os.path.basename(s)}" for s in sessions))
     t0 = time.time()
-    for i, s in enumerate(sessions, 1):
-        print(f"\n[{i}/{len(sessions)}] {os.path.basename(s)}")
-        written = session.process_session(s, psf, args.output_dir, kind=args.kind)
-        if args.metrics and args.kind == "mono_cal_target":
-            for out_dir in written:
-                session.write_metrics(out_dir)
-    print(f"\nAll sessions done in {(time.time() - t0) / 60:.1f} min")
+    metrics_cb = session.write_metrics if (args.metrics and args.kind == "mono_cal_target") else None
+    session.process_sessions(sessions, psf, args.output_dir, args.kind, rank=rank, world=world, on_written=metrics_cb)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(f"\nAll sessions done in {(time.time() - t0) / 60:.1f} min" + (f" on {world} GPUs" if world > 1 else ""))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

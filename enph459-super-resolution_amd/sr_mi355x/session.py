@@ -151,25 +151,102 @@ def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step
     return {"native_2x": native, "SAA": saa[0], "SAA_IBP": hr[0], "LR_mean": mean_lr}, [float(e) for e in errs[0].cpu()]
 
 
+def reconstruct_batch(frame_sets, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step=IBP_STEP_SIZE):
+    """`reconstruct` for B frame sets of one shape and one shift table in ONE library call per stage (B = the reps of a
+    barcode session, mono_barcodes/run_sr.py:301-351: independent work items).  Every item's result is bit-identical to
+    reconstruct() on that item alone (the kernels treat batch entries independently; tests/test_gpu_session.py).
+    -> list of (images dict, MSE trace), one per frame set."""
+    import torch
+    lr64 = torch.stack([torch.stack(fr) for fr in frame_sets])  # [B, N, h, w] float64
+    B, N, h, w = lr64.shape
+    with _loader_precision():
+        mean_lr = api.mean_frames_batched(lr64)
+    lr = lr64.to(api._TORCH_DT[api.get_precision()])
+    native = api.zoom_batched(mean_lr, factor)
+    saa = api.shift_and_add_batched(lr, shifts, factor)
+    hr, errs = api.ibp_batched(lr, shifts, psf_kernel, saa.clone(), factor, n_iter, step)
+    errs = errs.cpu()
+    return [({"native_2x": native[i], "SAA": saa[i], "SAA_IBP": hr[i], "LR_mean": mean_lr[i]}, [float(e) for e in errs[i]])
+            for i in range(B)]
+
+
+class Prefetcher:
+    """Host work of item k + 1 (PNG decode, uint8 -> device) overlapped with the device work of item k: a worker thread runs
+    `load(item)` for the next item while the caller consumes the current one.  PIL releases the GIL while it inflates a PNG,
+    and the host-to-device copies it issues go to the thread's own stream, so neither blocks the compute stream."""
+
+    def __init__(self, items, load):
+        import concurrent.futures
+        self._items, self._load = list(items), load
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        self._next = self._pool.submit(self._guarded, self._items[0]) if self._items else None
+
+    def _guarded(self, item):
+        import torch
+        if torch.cuda.is_available():
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                out = self._load(item)
+            stream.synchronize()
+            return out
+        return self._load(item)
+
+    def __iter__(self):
+        for k, item in enumerate(self._items):
+            cur = self._next.result()
+            self._next = self._pool.submit(self._guarded, self._items[k + 1]) if k + 1 < len(self._items) else None
+            yield item, cur
+        self._pool.shutdown()
+
+
+PNG_COMPRESS_LEVEL = 1  # zlib level of the PNGs written (PIL's default is 6: ~4x the encode time for ~10 % smaller files; lossless either way)
+_writers, _pending = None, []
+
+
+def _writer_pool():
+    global _writers
+    if _writers is None:
+        import concurrent.futures
+        _writers = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+    return _writers
+
+
+def flush_writes():
+    """Wait for the PNG encodes queued by _save_outputs (they run on worker threads: zlib releases the GIL)."""
+    global _pending
+    pend, _pending = _pending, []
+    for f in pend:
+        f.result()
+
+
 def _save_outputs(out_dir, images, errors, lr_name, extra=None):
+    """Quantise on the device (clip + truncate, run_sr.py:303), copy the uint8 planes to the host, and hand the PNG encoding to
+    worker threads; done.flag is written by the last of them, after every file of the directory exists."""
     from PIL import Image
     os.makedirs(out_dir, exist_ok=True)
-    for name in ("native_2x", "SAA", "SAA_IBP"):
-        Image.fromarray(api.quantize_u8(images[name]).cpu().numpy()).save(os.path.join(out_dir, f"{name}.png"))
+    planes = {f"{name}.png": api.quantize_u8(images[name]).cpu().numpy() for name in ("native_2x", "SAA", "SAA_IBP")}
     with _loader_precision():
-        Image.fromarray(api.quantize_u8(images["LR_mean"]).cpu().numpy()).save(os.path.join(out_dir, lr_name))
-    with open(os.path.join(out_dir, "convergence.json"), "w") as fp:
-        json.dump({"ibp_mse": errors}, fp)
-    if extra:
-        for fname, obj in extra.items():
-            with open(os.path.join(out_dir, fname), "w") as fp:
-                json.dump(obj, fp, indent=2)
-    open(os.path.join(out_dir, "done.flag"), "w").close()
+        planes[lr_name] = api.quantize_u8(images["LR_mean"]).cpu().numpy()
+
+    def job():
+        for fname, arr in planes.items():
+            Image.fromarray(arr).save(os.path.join(out_dir, fname), compress_level=PNG_COMPRESS_LEVEL)
+        with open(os.path.join(out_dir, "convergence.json"), "w") as fp:
+            json.dump({"ibp_mse": errors}, fp)
+        if extra:
+            for fname, obj in extra.items():
+                with open(os.path.join(out_dir, fname), "w") as fp:
+                    json.dump(obj, fp, indent=2)
+        open(os.path.join(out_dir, "done.flag"), "w").close()
+
+    _pending.append(_writer_pool().submit(job))
 
 
-def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None, verbose=True):
+def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None, verbose=True, batch_reps=True, loaded=None, flush=True):
     """Counterpart of process_session / process_combo.  Returns the list of output directories written
-    (empty if everything was already done)."""
+    (empty if everything was already done).  batch_reps: the reps of a barcode session that are still to do go through the
+    library in one B = reps call (reconstruct_batch) instead of one call per rep; `loaded`: frames already decoded by a
+    Prefetcher (what load_corner_reps / load_mono_cal_session / load_rgb_cal_combo would return)."""
     kind = kind or detect_kind(session_dir)
     if kind not in IBP_ITERATIONS:
         raise ValueError("kind must be one of " + ", ".join(IBP_ITERATIONS))
@@ -183,28 +260,75 @@ def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None
             say(f"  [skip] {name} - already done")
             return written
         if kind == "mono_cal_target":
-            frames, shifts = load_mono_cal_session(session_dir)
+            frames, shifts = loaded or load_mono_cal_session(session_dir)
             lr_name, extra = "LR_mean.png", None
         else:
-            frames, shifts = load_rgb_cal_combo(session_dir)
+            frames, shifts = loaded or load_rgb_cal_combo(session_dir)
             lr_name = "LR_red_mean.png"
             extra = {"shifts.json": {"shifts_lr_yx": [list(s) for s in shifts], "corner_labels": CORNER_ORDER}}
         images, errors = reconstruct(frames, shifts, psf_kernel, n_iter)
         _save_outputs(out_dir, images, errors, lr_name, extra)
+        if flush:
+            flush_writes()
         say(f"  Output: {out_dir}")
         written.append(out_dir)
         return written
     red = kind == "rgb_barcodes"
-    all_reps, shifts = load_corner_reps(session_dir, red)
+    all_reps, shifts = loaded or load_corner_reps(session_dir, red)
+    todo = []
     for rep_idx, frames in enumerate(all_reps):
         out_dir = os.path.join(output_base, name, f"rep{rep_idx}")
         if os.path.exists(os.path.join(out_dir, "done.flag")):
             say(f"  [skip] rep {rep_idx} - already done")
             continue
-        images, errors = reconstruct(frames, shifts, psf_kernel, n_iter)
+        todo.append((out_dir, frames))
+    if not todo:
+        return written
+    if batch_reps:
+        results = reconstruct_batch([fr for _, fr in todo], shifts, psf_kernel, n_iter)
+    else:
+        results = [reconstruct(fr, shifts, psf_kernel, n_iter) for _, fr in todo]
+    for (out_dir, _), (images, errors) in zip(todo, results):
         _save_outputs(out_dir, images, errors, "LR_red_mean.png" if red else "LR_mean.png")
         say(f"    Output: {out_dir}")
         written.append(out_dir)
+    if flush:
+        flush_writes()
+    return written
+
+
+def load_session(session_dir, kind):
+    """The host + upload half of process_session (what a Prefetcher runs ahead): decoded frames on the device."""
+    if kind == "mono_cal_target":
+        return load_mono_cal_session(session_dir)
+    if kind == "rgb_cal_target":
+        return load_rgb_cal_combo(session_dir)
+    return load_corner_reps(session_dir, kind == "rgb_barcodes")
+
+
+def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None):
+    """The reference's outer loop (mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301) over the sessions this
+    rank owns (session i -> rank i mod world, parallel.shard_indices: independent items, no collective), with the PNG decode
+    and upload of session k + 1 overlapped with the device work of session k.  -> output directories written by this rank."""
+    from . import parallel
+    mine = [sessions[i] for i in parallel.shard_indices(len(sessions), rank, world)]
+    say = print if verbose else (lambda *a, **k: None)
+    written = []
+
+    def load(sdir):
+        name = os.path.basename(os.path.normpath(sdir))
+        if kind in ("mono_cal_target", "rgb_cal_target") and os.path.exists(os.path.join(output_base, name, "done.flag")):
+            return None  # process_session will skip it: do not decode
+        return load_session(sdir, kind)
+
+    for k, (sdir, loaded) in enumerate(Prefetcher(mine, load), 1):
+        say(f"\n[rank {rank}: {k}/{len(mine)}] {os.path.basename(sdir)}")
+        out = process_session(sdir, psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded, flush=on_written is not None)
+        if on_written:
+            for d in out:
+                on_written(d)
+        written += out
+    flush_writes()  # the PNG encodes of session k ran beside the device work of session k + 1
     return written
 
 

@@ -93,3 +93,69 @@ def test_barcode_reps(tmp_path, g_real):
         hr, _ = O.ibp(list(lr), session.CORNER_SHIFTS, g_real["psf_g"], saa, 2, 3, 0.5)
         same_u8(os.path.join(d, "SAA.png"), saa)
         same_u8(os.path.join(d, "SAA_IBP.png"), hr)
+
+
+def _png_bytes(d):
+    return {n: open(os.path.join(d, n), "rb").read() for n in ("native_2x.png", "SAA.png", "SAA_IBP.png", "LR_mean.png")}
+
+
+def test_barcode_reps_batched_equals_per_rep(tmp_path, g_real):
+    """The reps of a barcode session in ONE B = reps library call (reconstruct_batch) give, file for file and bit for bit, what one
+    call per rep gives (mono_barcodes/run_sr.py:301-351 processes them one after the other); a rep already done is skipped and
+    the rest still batched; the prefetching multi-session loop writes the same files."""
+    frames = g_real["mono_tl_lr"][1:]
+    for sname in ("bc_a", "bc_b"):
+        sess = tmp_path / "data" / sname
+        sess.mkdir(parents=True)
+        for rep in range(3):
+            for c in range(4):
+                Image.fromarray(np.roll(frames[c], rep + (5 if sname == "bc_b" else 0), axis=1)).save(sess / f"corner{c}_rep{rep:02d}.png")
+    sa = str(tmp_path / "data" / "bc_a")
+    one = session.process_session(sa, g_real["psf_g"], str(tmp_path / "per_rep"), kind="mono_barcodes", n_iter=6, verbose=False, batch_reps=False)
+    bat = session.process_session(sa, g_real["psf_g"], str(tmp_path / "batched"), kind="mono_barcodes", n_iter=6, verbose=False)
+    assert [os.path.basename(w) for w in bat] == ["rep0", "rep1", "rep2"] and len(one) == 3
+    for a, b in zip(one, bat):
+        assert _png_bytes(a) == _png_bytes(b)
+        assert json.load(open(os.path.join(a, "convergence.json"))) == json.load(open(os.path.join(b, "convergence.json")))
+    # rep1 already done elsewhere: skipped, rep0 and rep2 still go through one call
+    part = tmp_path / "partial" / "bc_a" / "rep1"
+    part.mkdir(parents=True)
+    (part / "done.flag").write_text("")
+    got = session.process_session(sa, g_real["psf_g"], str(tmp_path / "partial"), kind="mono_barcodes", n_iter=6, verbose=False)
+    assert [os.path.basename(w) for w in got] == ["rep0", "rep2"]
+    assert _png_bytes(got[1]) == _png_bytes(bat[2])
+    # the multi-session loop (host decode of the next session overlapped with the device work of the current one), and its
+    # two-rank sharding: rank 0 of 2 owns session 0, rank 1 session 1
+    sessions = session.discover_sessions(str(tmp_path / "data"), "mono_barcodes")
+    assert [os.path.basename(s) for s in sessions] == ["bc_a", "bc_b"]
+    all_w = session.process_sessions(sessions, g_real["psf_g"], str(tmp_path / "loop"), "mono_barcodes", n_iter=6, verbose=False)
+    assert len(all_w) == 6 and _png_bytes(all_w[2]) == _png_bytes(bat[2])
+    r1 = session.process_sessions(sessions, g_real["psf_g"], str(tmp_path / "rank1"), "mono_barcodes", n_iter=6, verbose=False, rank=1, world=2)
+    assert len(r1) == 3 and all("bc_b" in w for w in r1) and _png_bytes(r1[0]) == _png_bytes(all_w[3])
+
+
+def test_run_sr_two_ranks_on_one_gpu(tmp_path, g_real):
+    """`python -m sr_mi355x.run_sr` under torch.distributed.run with two ranks (both on cuda:0 here; one GPU each on a node):
+    session i goes to rank i mod 2, no collective on the data path, the files equal a single-process run's."""
+    import subprocess
+    import sys
+    frames = g_real["mono_tl_lr"][1:]
+    for k, sname in enumerate(("s0", "s1", "s2")):
+        sess = tmp_path / "data" / sname
+        sess.mkdir(parents=True)
+        for rep in range(2):
+            for c in range(4):
+                Image.fromarray(np.roll(frames[c], rep + 3 * k, axis=0)).save(sess / f"corner{c}_rep{rep:02d}.png")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRX_ONE_GPU="1", PYTHONPATH=os.path.join(root, "enph459-super-resolution_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    args = ["-m", "sr_mi355x.run_sr", "--kind", "mono_barcodes", "--data-dir", str(tmp_path / "data")]
+    one = subprocess.run([sys.executable] + args + ["--output-dir", str(tmp_path / "one")], capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541"] + args + ["--output-dir", str(tmp_path / "two")], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    assert "on 2 GPUs" in two.stdout and "[rank 1: 1/1] s1" in two.stdout and "[rank 0: 2/2] s2" in two.stdout
+    for sname in ("s0", "s1", "s2"):
+        for rep in ("rep0", "rep1"):
+            assert _png_bytes(str(tmp_path / "one" / sname / rep)) == _png_bytes(str(tmp_path / "two" / sname / rep))
