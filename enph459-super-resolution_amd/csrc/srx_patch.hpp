@@ -221,6 +221,13 @@ __global__ void __launch_bounds__(256)
 // in: a[i] = element (i, lane).  out: r[j] = element (lane, j).  (Rows / columns are abstract: the same routine goes back.)
 __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64], float *Tw, int lane)
 {
+    // r[] is written under a lane predicate (each half of the wave reads its rows in its own pass).  A predicated write keeps the
+    // other lanes' previous contents, so without a full definition here the compiler must treat r[] as live from wherever it was
+    // last written -- across the whole preceding stage, and around the iteration loop: 64 registers pinned beside the 64 of the
+    // working plane, which is where the kernel's ~150 spills per iteration came from.  An empty asm defines every element at no cost.
+#pragma unroll
+    for (int j = 0; j < 64; j++)
+        asm volatile("" : "=v"(r[j]));
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -394,22 +401,35 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
     Rown[s6 + 256 + lane] = a[62];
     Rown[s6 + 320 + lane] = a[63];
     __syncthreads();
-    float x[70];
-    x[0] = x[1] = x[2] = x[67] = x[68] = x[69] = 0.f;
+    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
     if (!first)
-        x[0] = Rprev[s6 + 192 + lane], x[1] = Rprev[s6 + 256 + lane], x[2] = Rprev[s6 + 320 + lane];
+        hl[0] = Rprev[s6 + 192 + lane], hl[1] = Rprev[s6 + 256 + lane], hl[2] = Rprev[s6 + 320 + lane];
     if (!last)
-        x[67] = Rnext[s6 + lane], x[68] = Rnext[s6 + 64 + lane], x[69] = Rnext[s6 + 128 + lane];
+        hr[0] = Rnext[s6 + lane], hr[1] = Rnext[s6 + 64 + lane], hr[2] = Rnext[s6 + 128 + lane];
+    // In place, 8 outputs at a time: besides a[] only the 14-value window and the three old values the next group still needs
+    // are live, and a scheduling fence after every group keeps the compiler from interleaving more outputs than the registers hold
+    // (left alone it trades ~30 spilled registers per blur for instruction-level parallelism).
+    float c0 = hl[0], c1 = hl[1], c2 = hl[2];
 #pragma unroll
-    for (int j = 0; j < 64; j++)
-        x[3 + j] = a[j];
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+        float w[14];
+        w[0] = c0, w[1] = c1, w[2] = c2;
 #pragma unroll
-    for (int j = 0; j < 64; j++) {
-        float acc = kb[0] * x[j];
+        for (int j = 0; j < 8; j++)
+            w[3 + j] = a[j0 + j];
 #pragma unroll
-        for (int k = 1; k < 7; k++)
-            acc = fmaf(kb[k], x[j + k], acc);
-        a[j] = acc;
+        for (int j = 0; j < 3; j++)
+            w[11 + j] = j0 + 8 + j < 64 ? a[j0 + 8 + j] : hr[j];
+        c0 = w[8], c1 = w[9], c2 = w[10];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float acc = kb[0] * w[j];
+#pragma unroll
+            for (int k = 1; k < 7; k++)
+                acc = fmaf(kb[k], w[j + k], acc);
+            a[j0 + j] = acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -468,22 +488,22 @@ __global__ void __launch_bounds__(1024)
     }
     for (int it = 0; it < n_iter; it++) {
         float r[64];
-        // everything derived from the lane index is re-derived per iteration from an opaque copy: hoisted out of the loop, the
-        // ~45 lane-dependent addresses and predicates do not fit beside the working plane and were spilled, one scratch
-        // round trip per use
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, l4 = lane * 4;
-        const bool wrapped = exy && s == 3 && lane == 63;  // row layout: this lane holds row -1
-        const int gy = wrapped ? -1 : 64 * s + lane;       // row layout: natural row of this lane
-        const bool rownear = wrapped || gy < nby;
-        const float crow = C01 ? (float)((rmask >> lane) & 1ull) : 0.f;
+        // Everything derived from the lane index (LDS and global addresses, predicates) and from the block offsets is re-derived
+        // PER STAGE from opaque copies.  Left to itself the compiler computes all of it once -- at the top of the loop, or above it
+        // -- and carries ~55 registers of addresses across stages whose working plane needs the file: they were spilled, one
+        // scratch round trip per use (the spill traffic was as large as the kernel's real traffic).
+#define SRX_STAGE_LOCALS()                                 \
+    int tid = tid0;                                        \
+    asm volatile("" : "+v"(tid));                          \
+    const int lane = tid & 63, l4 = lane * 4;              \
+    int cbl = cb0, tbl = tb0, m8l = (16 * u * PN + 64 * s) * 4; \
+    asm volatile("" : "+s"(cbl), "+s"(tbl), "+s"(m8l));    \
+    (void)tbl, (void)m8l, (void)cbl, (void)l4
+        float yex = 0.f;
+        {  // ---------------- stage A ----------------
+        SRX_STAGE_LOCALS();
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(0);
-        // opaque copies of the block offsets: otherwise every row / column offset derived from them is hoisted out of this
-        // loop and kept (and spilled) in scalar registers
-        int cbl = cb0, tbl = tb0, m8l = (16 * u * PN + 64 * s) * 4;
-        asm volatile("" : "+s"(cbl), "+s"(tbl), "+s"(m8l));
         // ================= stage A: column layout, lane = column 64 u + lane, a[i] = row 64 s + i =================
 #pragma unroll
         for (int i = 0; i < 64; i++)
@@ -491,7 +511,6 @@ __global__ void __launch_bounds__(1024)
         blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(1);
-        float yex = 0.f;
         fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1, SLOT0, lane, sload8(awy + 16), yex);
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(2);
@@ -505,17 +524,24 @@ __global__ void __launch_bounds__(1024)
         transpose64(a, r, Rown, lane);
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(4);
+        }
+        float sq = 0.f;
+        {  // ---------------- stage B ----------------
+        SRX_STAGE_LOCALS();
+        const bool wrapped = exy && s == 3 && lane == 63;  // row layout: this lane holds row -1
+        const int gy = wrapped ? -1 : 64 * s + lane;       // row layout: natural row of this lane
+        const bool rownear = wrapped || gy < nby;
+        const float crow = C01 ? (float)((rmask >> lane) & 1ull) : 0.f;
         // ================= stage B: row layout, lane = row 64 s + lane, r[j] = column 64 u + j =================
         blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
         __builtin_amdgcn_sched_barrier(0);
-        // operands of the G step and of the near band, in flight during the H-fwd chain (issued after the blur: its 70-register window is this stage's peak)
-        const __amdgpu_buffer_rsrc_t rsM8 = fused::plane_rsrc(tb.Mt8 + (size_t)b * (PN / 4) * PN, (size_t)(PN / 4) * PN);
-        unsigned m8w[16];
-        if (m8) {
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                m8w[k] = __builtin_amdgcn_raw_buffer_load_b32(rsM8, l4 + (k & 3) * PN * 4, m8l + (k >> 2) * PN * 16, 0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(5);
+        float yexx = 0.f;  // Y[gy, -1] (u == 0)
+        fwd_chain(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT1, SLOT0, lane, sload8(awx + 16), yexx);
+        __builtin_amdgcn_sched_barrier(0);
+        SRX_PSTAMP(6);
+        // ---- near-band descriptors: consumed behind the strips' barrier (the strip stores and the barrier cover their latency)
         uint2 nr0 = make_uint2(0, 0), nr1 = make_uint2(0, 0), ne0 = make_uint2(0, 0), ne1 = make_uint2(0, 0);
         float2 nm0 = make_float2(0.f, 0.f), nm1 = make_float2(0.f, 0.f);
         const bool n0 = tid < nn, n1 = tid + 1024 < nn;
@@ -523,12 +549,6 @@ __global__ void __launch_bounds__(1024)
             nr0 = tb.nrec[tid], ne0 = tb.nent[tid], nm0 = tb.Mn[(size_t)b * NN_PAD + tid];
         if (n1)
             nr1 = tb.nrec[tid + 1024], ne1 = tb.nent[tid + 1024], nm1 = tb.Mn[(size_t)b * NN_PAD + tid + 1024];
-        __builtin_amdgcn_sched_barrier(0);
-        SRX_PSTAMP(5);
-        float yexx = 0.f;  // Y[gy, -1] (u == 0)
-        fwd_chain(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT1, SLOT0, lane, sload8(awx + 16), yexx);
-        __builtin_amdgcn_sched_barrier(0);
-        SRX_PSTAMP(6);
         // ---- near-band strips of Y
         {
             const bool toprow = wrapped || (s == 0 && lane <= nby);
@@ -551,10 +571,17 @@ __global__ void __launch_bounds__(1024)
             }
         }
         __syncthreads();
+        // the LR mosaic of the G step: in flight during the near-band phase
+        const __amdgpu_buffer_rsrc_t rsM8 = fused::plane_rsrc(tb.Mt8 + (size_t)b * (PN / 4) * PN, (size_t)(PN / 4) * PN);
+        unsigned m8w[16];
+        if (m8) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                m8w[k] = __builtin_amdgcn_raw_buffer_load_b32(rsM8, l4 + (k & 3) * PN * 4, m8l + (k >> 2) * PN * 16, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(7);
         // ---- near band: G = M - sum of the listed Y samples; the counted samples' share of the MSE trace
-        float sq = 0.f;
         {
             auto near_px = [&](uint2 nr, uint2 ne, float2 nm, int t) {
                 const int cnt = nr.x & 255, cu = (nr.x >> 8) & 255, dst = nr.x >> 16;
@@ -687,6 +714,9 @@ __global__ void __launch_bounds__(1024)
         transpose64(a, r, Rown, lane);
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(12);
+        }
+        {  // ---------------- stage C ----------------
+        SRX_STAGE_LOCALS();
         // ================= stage C: column layout again, r[i] = row 64 s + i (row 63 of s == 3: the wrapped row -1) =================
         float hv[16], hw[16];  // the parked state, 16 rows at a time
         {
@@ -723,6 +753,8 @@ __global__ void __launch_bounds__(1024)
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(14);
+        }
+#undef SRX_STAGE_LOCALS
     }
     {
         const int l4 = (tid0 & 63) * 4;
