@@ -21,6 +21,9 @@
 #ifndef SRX_ZTILE_NSY
 #define SRX_ZTILE_NSY 1
 #endif
+#ifndef SRX_ZTILE_WPE
+#define SRX_ZTILE_WPE 3  // waves per SIMD the kernel is compiled for: 3 tiles of 4 waves per CU (170 registers), 4 would be 128
+#endif
 
 namespace srx {
 namespace ztile {
@@ -38,9 +41,14 @@ constexpr int NSY = SRX_ZTILE_NSY;            // block rows per tile: region hei
 constexpr int RGY = 64 * NSY, VTY = RGY - 2 * HALO;
 constexpr int SW = 4;             // strip pitch (rows of the top strip / columns of the left strip)
 // LDS: 16 wave regions of srx_patch.hpp (transpose image + exchange slots), then the near-band strips
-constexpr int OFF_YT = 4 * NSY * patch::RW, OFF_YL = OFF_YT + SW * RG, OFF_GT = OFF_YL + SW * RGY, OFF_GL = OFF_GT + SW * RG,
-              OFF_PART = OFF_GL + SW * RGY, LDS_WORDS = OFF_PART + 32;
-static_assert(LDS_WORDS * 4 <= (NSY == 1 ? 53 : NSY == 2 ? 80 : 160) * 1024, "LDS budget");
+// The strips are four rows of RG words (top band) / RGY rows of four words (left band).  They live in the parts of the wave regions
+// that neither the exchange slots ([0, 384) and [1024, 1408)) nor anything else uses between the two transposes: row k of the top
+// strips in region k at 384 (Y) and 640 (G), the left strips in regions 0 and 1 at 1408 (RGY * 4 <= 704 words) -- which keeps a
+// one-block-high tile at 33.9 KB, FOUR tiles per CU.
+constexpr int YT_OFF = 384, GT_OFF = 640, YL_OFF = 1408, GL_OFF = patch::RW + 1408;
+static_assert(SW <= 4 * NSY && 4 * RGY <= 704 && GT_OFF + RG <= patch::SLOT1 && YT_OFF + RG <= GT_OFF, "strip placement");
+constexpr int OFF_PART = 4 * NSY * patch::RW, LDS_WORDS = OFF_PART + 32;
+static_assert(LDS_WORDS * 4 <= (NSY == 1 ? 40 : NSY == 2 ? 80 : 160) * 1024, "LDS budget");
 
 struct ZArgs {
     int H, W, tiles_x, tiles_y;
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(256)
 // State and operand planes are zero-padded (image at (6, 6)), so no load is predicated; a store of a pixel this tile does not
 // own (or outside the image) goes to the plane's trash row / out of the buffer's range.
 // =========================================================================================================================
-__global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
+__global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart)
 {
     __shared__ float lds[LDS_WORDS];
@@ -216,7 +224,9 @@ __global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
     float *Rown = lds + wave * patch::RW;
     const float *Rup = lds + (wave - 4) * patch::RW, *Rdn = lds + (wave + 4) * patch::RW;
     const float *Rlf = lds + (wave - 1) * patch::RW, *Rrt = lds + (wave + 1) * patch::RW;
-    float *Yt = lds + OFF_YT, *Yl = lds + OFF_YL, *Gt = lds + OFF_GT, *Gl = lds + OFF_GL;
+    float *Yl = lds + YL_OFF, *Gl = lds + GL_OFF;
+    auto Yt = [&](int row, int col) -> float & { return lds[row * patch::RW + YT_OFF + col]; };
+    auto Gt = [&](int row, int col) -> float & { return lds[row * patch::RW + GT_OFF + col]; };
     double *part = reinterpret_cast<double *>(lds + OFF_PART);
     const float *awy = tb.aw[0].kb, *awx = tb.aw[1].kb;
     const size_t splane = (size_t)(HP + 1) * WP, oplane = (size_t)HP * WP;
@@ -265,7 +275,7 @@ __global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
         if (top && gy >= 0 && gy <= za.nby) {
 #pragma unroll
             for (int j = 0; j < 64; j++)
-                Yt[gy * RG + 64 * u + j] = r[j];
+                Yt(gy, 64 * u + j) = r[j];
         }
         if (left && u == 0) {
 #pragma unroll
@@ -282,7 +292,7 @@ __global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
             if (t < ntop) {
                 const int rw = t / RG, cc = t - rw * RG;
                 ngy = rw - za.exy, ngx = gx0 + cc;
-                dst = Gt + rw * RG + cc;
+                dst = &Gt(rw, cc);
             } else {
                 const int q = t - ntop, rw = q / za.LN, cc = q - rw * za.LN;
                 ngy = pr0 - HALO + rw, ngx = cc - za.exx;
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
             const int cnt = rec & 255, cu = rec >> 8;
             const float2 nm = tb.Mn[(size_t)b * NT + T];
             auto Yat = [&](int ry, int rx) -> float {  // natural, clamped coordinates -> the strip holding them
-                return ngy < za.nby ? Yt[ry * RG + rx - gx0] : Yl[(ry - (pr0 - HALO)) * SW + rx];
+                return ngy < za.nby ? Yt(ry, rx - gx0) : Yl[(ry - (pr0 - HALO)) * SW + rx];
             };
             float ys = 0.f;
             for (int g = 0; 4 * g < cnt; g++) {
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(256 * NSY, NSY == 1 ? 3 : 4)
         }
         sq += (rowown && rowin && gy >= za.nby) ? sqf : 0.f;
         if (top && gy >= 0 && gy < za.nby) {
-            const float *src = Gt + (gy + za.exy) * RG + 64 * u;  // zero outside the image (the near-band loop wrote every pixel)
+            const float *src = &Gt(gy + za.exy, 64 * u);  // zero outside the image (the near-band loop wrote every pixel)
 #pragma unroll
             for (int j = 0; j < 64; j++)
                 r[j] = src[j];

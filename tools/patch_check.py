@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """patch_check.py -- development check of the patch-resident IBP path (csrc/srx_patch.hpp) on the GPU box:
-k_ibp_patch against the CPU oracle and against the tile path (SRX_NO_PATCH=1) on C2-shaped patches, plus a timing.
+k_ibp_patch against the CPU oracle and against the tile path (FLAG_TILES) on C2-shaped patches, plus a timing.
 
     python tools/patch_check.py [B]
 """
@@ -22,11 +22,7 @@ from sr_mi355x import _lib  # noqa: E402
 
 
 def run(lr, shifts, psf, hr0, f, n_iter, patch):
-    if patch:
-        os.environ.pop("SRX_NO_PATCH", None)
-    else:
-        os.environ["SRX_NO_PATCH"] = "1"
-    hr, err = S.ibp_batched(lr, shifts, psf, hr0, f, n_iter, 0.5, precision="f32")
+    hr, err = S.ibp_batched(lr, shifts, psf, hr0, f, n_iter, 0.5, precision="f32", flags=S.FLAG_AUTO if patch else S.FLAG_TILES)
     path = _lib.load().srx_last_path().decode()
     torch.cuda.synchronize()
     return hr.double().cpu().numpy(), err.cpu().numpy(), path
@@ -62,14 +58,11 @@ def main():
     lr = torch.round(torch.rand((Bt, 16, 64, 64), device="cuda", generator=g) * 255)
     hr0 = torch.rand((Bt, 256, 256), device="cuda", generator=g) * 255
     for patch in (True, False):
-        if patch:
-            os.environ.pop("SRX_NO_PATCH", None)
-        else:
-            os.environ["SRX_NO_PATCH"] = "1"
         for rep in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            S.ibp_batched(lr, shifts, synth.gaussian_psf(), hr0, f, 80, 0.5, precision="f32", want_errors=True)
+            S.ibp_batched(lr, shifts, synth.gaussian_psf(), hr0, f, 80, 0.5, precision="f32", want_errors=True,
+                          flags=S.FLAG_AUTO if patch else S.FLAG_TILES)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         print(f"B={Bt} 80 iterations path={_lib.load().srx_last_path().decode()}: {dt * 1e3:.1f} ms  ({dt / 80 * 1e6:.0f} us / iteration)", flush=True)
