@@ -300,8 +300,8 @@ def main():
                             "(HIP events on the launch stream); traffic = PMC bytes of the iteration kernels per iteration"}
         tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (tools/collect_traffic.py)
         if os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get("workload") == f"{args.workload}:B={B}:{prec}":
+            tj = json.load(open(tf)).get("workloads", {}).get(f"{args.workload}:B={B}:{prec}")
+            if tj:
                 tr = sum(tj["kernels"][k]["hbm_bytes_per_iteration"] for k in it["kernels"] if k in tj["kernels"])
                 if tr and all(k in tj["kernels"] for k in it["kernels"]):
                     roofline["traffic"] = tr

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of
 `bench.py --steps 1 --warmup 0 --iters 4 --no-cpu-baseline --no-roofline` into profiles/traffic.json: HBM bytes
-per launch of each fused-path kernel.
+per launch of each kernel of one workload (the file holds one entry per workload tag; re-running replaces that entry).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports
 exactly half of the bytes actually fetched -- calibrated here on our own access pattern (4 B/lane loads):
@@ -34,9 +34,7 @@ PERSISTENT = ("k_ibp_patch",)  # one launch = all iterations
 def main():
     iters = int(sys.argv[4])
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"workload": sys.argv[3], "unit": "bytes per launch",
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
-           "kernels": {}}
+    out = {"iters": iters, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
@@ -45,7 +43,15 @@ def main():
         out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": nb,
                              "hbm_bytes_per_iteration": nb // iters if k in PERSISTENT else nb}
     dst = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
-    json.dump(out, open(dst, "w"), indent=1)
+    try:
+        doc = json.load(open(dst))
+        assert "workloads" in doc
+    except Exception:
+        doc = {"workloads": {}}
+    doc["unit"] = "bytes per launch"
+    doc["method"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"
+    doc["workloads"][sys.argv[3]] = out  # one entry per workload tag ("c2:B=1024:f32", "c3_mono:B=1:f32", ...)
+    json.dump(doc, open(dst, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
 

@@ -1,0 +1,38 @@
+#!/bin/bash
+# profile_round.sh TAG -- the rocprofv3 evidence of one round, collected on the GPU box in ONE gpurun call:
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r02'
+# For each of the two workloads bench.py reports a roofline for (C2 = k_ibp_patch, C3-mono = k_ibp_ztile):
+#   <wl>_stats : rocprofv3 --kernel-trace --stats            (per-kernel durations)
+#   <wl>_fetch : rocprofv3 --kernel-trace --pmc FETCH_SIZE   (separate pass, as MI355X_MICROARCH.md prescribes)
+#   <wl>_write : rocprofv3 --kernel-trace --pmc WRITE_SIZE
+#   <wl>_sq1/2 : SQ / GRBM counters (VALU and LDS activity, wave-cycle split)
+# Everything lands in gpurun_out/TAG/; tools/profile_collect.py TAG turns it into profiles/TAG_* afterwards (on the dev box).
+# The program after "--" is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
+set -e
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd /tmp
+export TMPDIR=/tmp
+COMMON="--steps 1 --no-cpu-baseline --no-roofline --no-secondary"
+SQ1="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
+SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
+for wl in c2 c3_mono; do
+    echo "== $wl kernel stats"
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${wl}_stats" -o run -- python3 "$R/bench.py" --workload $wl --warmup 1 $COMMON > "$O/${wl}_stats.log" 2>&1
+    echo "== $wl FETCH_SIZE"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/${wl}_fetch" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_fetch.log" 2>&1
+    echo "== $wl WRITE_SIZE"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/${wl}_write" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_write.log" 2>&1
+    echo "== $wl SQ pass 1"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d "$O/${wl}_sq1" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_sq1.log" 2>&1
+    echo "== $wl SQ pass 2"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d "$O/${wl}_sq2" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_sq2.log" 2>&1
+done
+echo "== bench lines"
+cd "$R"
+timeout -k 10 500 python3 bench.py --steps 3 --warmup 1 > "$O/c2_bench.json" 2> "$O/c2_bench.err"
+timeout -k 10 200 python3 bench.py --workload c3_mono --steps 3 --warmup 1 --no-cpu-baseline > "$O/c3_mono_bench.json" 2> "$O/c3_mono_bench.err"
+tail -c 600 "$O/c2_bench.json"
+echo PROFILE_ROUND_DONE

@@ -17,7 +17,7 @@ from sr_mi355x import _lib, synth  # noqa: E402
 f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), int(os.environ.get("STAMPS_B", "1024"))
 lr = torch.rand((B, 16, 64, 64), device="cuda") * 255
 saa = S.shift_and_add_batched(lr, shifts, f)
-S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
+S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5, flags=S.FLAG_TILES)  # the mosaic tile kernels (the default is k_ibp_patch)
 # one rgb_cal_target-shaped frame through the per-frame fused path (k_bwd_tile)
 lr1 = torch.rand((1, 4, 768, 1024), device="cuda") * 255
 saa1 = S.shift_and_add_batched(lr1, synth.MEASURED_4, 2)
@@ -37,6 +37,9 @@ for k, (kn, ph) in names.items():
     last = len(ph) - 1
     ok = (t[0, :nb] > 0) & (t[last, :nb] > t[0, :nb])
     tot = (t[last, :nb] - t[0, :nb])[ok]
+    if not ok.sum():
+        print(f"{kn}: not run")
+        continue
     print(f"{kn}: blocks {ok.sum()}, median cycles/block {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f})")
     for i in range(last):
         d = (t[i + 1, :nb] - t[i, :nb])[ok]
