@@ -182,9 +182,12 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
         out["iteration"] = {"algorithmic_bytes": it_bytes, "kernels": {k: round(v, 2) for k, v in sorted(per_iter.items())},
                             "kernel_time_us": round(t_iter_us, 2), "achieved": round(it_bytes / (t_iter_us * 1e-6) / 1e9, 1),
                             "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        out["dominant"] = {"kernel": dom, "avg_launch_us": kernels[dom]["avg_us"], "algorithmic_bytes_per_launch": nbytes,
-                           "achieved": round(nbytes / (kernels[dom]["avg_us"] * 1e-6) / 1e9, 1) if nbytes else None,
-                           "frac": round(nbytes / (kernels[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if nbytes else None}
+        # k_ibp_patch runs as a pair of launches (byte / float form of the mosaic; a patch is iterated by exactly one of them, the
+        # other's blocks leave at once): "one launch" of the roofline is the pair
+        launch_us = round(kernels[dom]["total_ms"] * 1e3, 2) if dom == "k_ibp_patch" else kernels[dom]["avg_us"]
+        out["dominant"] = {"kernel": dom, "avg_launch_us": launch_us, "algorithmic_bytes_per_launch": nbytes,
+                           "achieved": round(nbytes / (launch_us * 1e-6) / 1e9, 1) if nbytes else None,
+                           "frac": round(nbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if nbytes else None}
     return out
 
 

@@ -217,24 +217,29 @@ __global__ void __launch_bounds__(256)
     Mn[(size_t)b * NN_PAD + t] = make_float2(Mg[((size_t)b * Wg + ngy + 13) * Wg + ngx + 13], Mu[(size_t)b * NB + ni]);
 }
 
+// two consecutive words through a buffer descriptor (32-bit lane offset; out of range reads 0)
+__device__ __forceinline__ uint2 ld_u2(__amdgpu_buffer_rsrc_t rs, int byte_off)
+{
+    return make_uint2(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0), __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off + 4, 0, 0));
+}
+
 // ---- wave-private 64 x 64 transpose through a 32-row LDS image ----------------------------------------------------------
 // in: a[i] = element (i, lane).  out: r[j] = element (lane, j).  (Rows / columns are abstract: the same routine goes back.)
 __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64], float *Tw, int lane)
 {
-    // r[] is written under a lane predicate (each half of the wave reads its rows in its own pass).  A predicated write keeps the
-    // other lanes' previous contents, so without a full definition here the compiler must treat r[] as live from wherever it was
-    // last written -- across the whole preceding stage, and around the iteration loop: 64 registers pinned beside the 64 of the
-    // working plane, which is where the kernel's ~150 spills per iteration came from.  An empty asm defines every element at no cost.
-#pragma unroll
-    for (int j = 0; j < 64; j++)
-        asm volatile("" : "=v"(r[j]));
+    // Each half of the wave reads its rows in its own pass, so r[] is written under a lane predicate -- and a predicated write
+    // keeps the other lanes' previous contents: without a full definition the compiler must treat r[] as live from wherever it was
+    // last written, across the whole preceding stage and around the iteration loop (64 registers pinned beside the 64 of the
+    // working plane: ~150 spills per iteration).  So pass 0 reads UNPREDICATED: the upper half-wave re-reads the lower half's
+    // rows (same addresses, no bank conflict), which defines every element exactly where its life should start -- after pass 0
+    // has parked a[0..31], not before (an up-front definition keeps 128 registers live through the first 32 stores).
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int i = 0; i < 32; i++)
             Tw[i * TSD + lane] = a[32 * h + i];
         __builtin_amdgcn_wave_barrier();
-        if ((lane >> 5) == h) {
+        if (h == 0 || (lane >> 5) == h) {
             const float2 *row = reinterpret_cast<const float2 *>(Tw + (lane & 31) * TSD);
 #pragma unroll
             for (int k = 0; k < 32; k++) {
@@ -448,7 +453,7 @@ __global__ void k_patch_params(AxisWPair v, AxisW *dst)
     dst[1] = v.x;
 }
 
-template <bool C01>
+template <bool C01, bool M8>
 __global__ void __launch_bounds__(1024)
     k_ibp_patch(const float *__restrict__ hr_in, float *__restrict__ hr_out, PatchTabs tb, PatchArgs pa, const double *__restrict__ Vtot,
                 double scale, double *__restrict__ errors, int n_iter)
@@ -467,7 +472,12 @@ __global__ void __launch_bounds__(1024)
 
     const __amdgpu_buffer_rsrc_t rs_in = fused::plane_rsrc(hr_in + (size_t)b * PN * PN, (size_t)PN * PN);
     const __amdgpu_buffer_rsrc_t rs_out = fused::plane_rsrc(hr_out + (size_t)b * PN * PN, (size_t)PN * PN);
-    const int m8 = __builtin_amdgcn_readfirstlane(tb.m8[b]);
+    // The byte form of the mosaic (M8) and the float form are two instantiations, launched one after the other; a block whose patch
+    // belongs to the other one leaves at once.  (As a run-time branch inside one kernel the two G steps cost 40 more spilled
+    // registers per iteration: the allocator sees the pressure of both.)
+    if ((__builtin_amdgcn_readfirstlane(tb.m8[b]) != 0) != M8)
+        return;
+    constexpr int m8 = M8 ? 1 : 0;
     const float *awy = tb.aw[0].kb, *awx = tb.aw[1].kb;  // 24 floats each: kb | kt | wfb
     const int nn = pa.nn;
     const float sn = pa.sn;
@@ -545,10 +555,17 @@ __global__ void __launch_bounds__(1024)
         uint2 nr0 = make_uint2(0, 0), nr1 = make_uint2(0, 0), ne0 = make_uint2(0, 0), ne1 = make_uint2(0, 0);
         float2 nm0 = make_float2(0.f, 0.f), nm1 = make_float2(0.f, 0.f);
         const bool n0 = tid < nn, n1 = tid + 1024 < nn;
-        if (n0)
-            nr0 = tb.nrec[tid], ne0 = tb.nent[tid], nm0 = tb.Mn[(size_t)b * NN_PAD + tid];
-        if (n1)
-            nr1 = tb.nrec[tid + 1024], ne1 = tb.nent[tid + 1024], nm1 = tb.Mn[(size_t)b * NN_PAD + tid + 1024];
+        // (through buffer descriptors: one 32-bit lane offset instead of three 64-bit lane addresses, which did not survive the
+        // stage in registers; a lane past the list reads zeros)
+        const __amdgpu_buffer_rsrc_t rsNr = fused::plane_rsrc(tb.nrec, (size_t)nn), rsNe = fused::plane_rsrc(tb.nent, (size_t)pa.ngrp * NN_PAD),
+                                     rsMn = fused::plane_rsrc(tb.Mn + (size_t)b * NN_PAD, (size_t)nn);
+        {
+            const int t8 = tid * 8;
+            nr0 = ld_u2(rsNr, t8), ne0 = ld_u2(rsNe, t8);
+            nr1 = ld_u2(rsNr, t8 + 8192), ne1 = ld_u2(rsNe, t8 + 8192);
+            const uint2 m0 = ld_u2(rsMn, t8), m1 = ld_u2(rsMn, t8 + 8192);
+            nm0 = make_float2(__uint_as_float(m0.x), __uint_as_float(m0.y)), nm1 = make_float2(__uint_as_float(m1.x), __uint_as_float(m1.y));
+        }
         // ---- near-band strips of Y
         {
             const bool toprow = wrapped || (s == 0 && lane <= nby);
@@ -588,7 +605,7 @@ __global__ void __launch_bounds__(1024)
                 float ys = (cnt > 0 ? Ystrip[ne.x & 0xffff] : 0.f) + (cnt > 1 ? Ystrip[ne.x >> 16] : 0.f) +
                            (cnt > 2 ? Ystrip[ne.y & 0xffff] : 0.f) + (cnt > 3 ? Ystrip[ne.y >> 16] : 0.f);
                 for (int g = 1; 4 * g < cnt; g++) {  // more than 4 frames on a pixel: the corner, or frames sharing a phase
-                    const uint2 e = tb.nent[(size_t)g * NN_PAD + t];
+                    const uint2 e = ld_u2(rsNe, (g * NN_PAD + t) * 8);
                     const int c = cnt - 4 * g;
                     ys += (c > 0 ? Ystrip[e.x & 0xffff] : 0.f) + (c > 1 ? Ystrip[e.x >> 16] : 0.f) + (c > 2 ? Ystrip[e.y & 0xffff] : 0.f) +
                           (c > 3 ? Ystrip[e.y >> 16] : 0.f);
@@ -881,10 +898,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     hipLaunchKernelGGL(k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
     PatchTabs tb{Mt, Mt8, m8, Ct, aw, nrec, nent, Mn};
-    if (pa.c01)
-        SRX_LAUNCH(KID_IBP_PATCH, k_ibp_patch<true>, dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
-    else
-        SRX_LAUNCH(KID_IBP_PATCH, k_ibp_patch<false>, dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+    // both mosaic forms over the whole batch: every patch is iterated by exactly one of the two launches (k_patch_prep's m8 flag)
+    if (pa.c01) {
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<true, true>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<true, false>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+    } else {
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<false, true>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<false, false>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+    }
     return SRX_OK;
 }
 

@@ -19,16 +19,19 @@ import json
 import sys
 
 
+PERSISTENT = ("k_ibp_patch",)  # one call = all iterations
+
+
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
             acc[name].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    # a PERSISTENT kernel is launched as a pair per call (two instantiations, every patch iterated by exactly one): per call = pair
+    return {k: sum(v) / (len(v) / 2 if k in PERSISTENT and len(v) % 2 == 0 else len(v)) for k, v in acc.items()}
 
 
-PERSISTENT = ("k_ibp_patch",)  # one launch = all iterations
 
 
 def main():

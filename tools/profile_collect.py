@@ -23,7 +23,8 @@ def one(pattern):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
+    n = name.split("(")[0].replace("void ", "")
+    return n.split("::")[-1] if "k_ibp_patch" in n else n.split("<")[0].split("::")[-1]  # keep k_ibp_patch's instantiations apart
 
 
 def counters(path):
