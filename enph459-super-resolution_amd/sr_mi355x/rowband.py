@@ -1,0 +1,183 @@
+"""One image across ranks by row bands (the stand-in for BASELINE.json's one-large-item configuration).
+
+The reference's IBP loop (mono_cal_target/run_sr.py:190-209) updates every HR pixel from a bounded neighbourhood: per iteration
+    hr -> blur (7x7: 3 rows) -> cubic-spline shift (4-tap FIR: 2 rows, |f * dy| rows of translation, and the recursive prefilter,
+    whose response decays as |z|^n, z = sqrt(3) - 2) -> every f-th row -> residual -> zero insertion -> the same shift and blur back.
+So rank r, which OWNS the HR rows [a_r, b_r) (cut on the LR lattice), iterates on the sub-image [a_r - halo, b_r + halo) as if it were
+a whole image; what it computes on its own rows equals the one-process result as long as the halo covers the iteration's reach
+    D = 2 * (3 + 2 + ceil(max |f * dy|) + R),   R = 24 rows (float64: |z|^24 = 2e-14) or 14 (float32: 1e-8)
+and after every iteration (or every m iterations with a halo of m * D rows) the halo rows are replaced by the neighbours' own rows:
+two point-to-point messages per neighbour and round (RCCL send/recv over xGMI on the GPUs; gloo in the CPU test), no collective on
+the data path.  The MSE trace (run_sr.py:202,206) is a sum over LR rows: each rank adds up its own rows' residuals, and ONE all-reduce
+of the [n_iter] vector at the end of the call completes it -- the trace never feeds back into the iteration.
+
+The compute behind the cut is an "engine" (duck-typed): `GpuEngine` below drives libsrx; the CPU test plugs in the oracle.  Nothing
+here imports the oracle.
+"""
+import math
+
+import numpy as np
+
+_R_TAIL = {"f64": 24, "f32": 14}
+
+
+def reach_rows(factor, shifts_yx, kernel_rows=7, precision="f64"):
+    """HR rows one IBP iteration reaches up and down (D above), rounded up to the LR lattice."""
+    dmax = max((abs(float(s[0])) for s in shifts_yx), default=0.0) * factor
+    d = 2 * (kernel_rows // 2 + 2 + int(math.ceil(dmax)) + _R_TAIL[precision])
+    return -(-d // factor) * factor
+
+
+def band_plan(h, factor, world, halo_rows):
+    """Cut h LR rows into `world` bands of whole LR rows.  Returns per rank (a, b, A, B): the owned HR rows [a, b) and the rows
+    [A, B) of the sub-image it iterates on.  halo_rows must be a multiple of `factor` and no band may be shorter than it (a halo
+    comes from the adjacent rank only)."""
+    if halo_rows % factor:
+        raise ValueError("halo_rows must be a multiple of the factor (the cut lies on the LR lattice)")
+    if world < 1 or h < world:
+        raise ValueError("more ranks than LR rows")
+    H = h * factor
+    base, extra = divmod(h, world)
+    plan, lo = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        a, b = lo * factor, (lo + n) * factor
+        if world > 1 and b - a < halo_rows:
+            raise ValueError(f"band of rank {r} ({b - a} HR rows) is shorter than the halo ({halo_rows}): use fewer ranks")
+        plan.append((a, b, max(0, a - halo_rows), min(H, b + halo_rows)))
+        lo += n
+    return plan
+
+
+class GpuEngine:
+    """libsrx on this rank's GPU: sub-images as [1, ...] batches through api.ibp_batched / api.forward_model_batched."""
+
+    def __init__(self, shifts_yx, kernel, factor, step, precision="f32"):
+        import torch
+        from . import api
+        self.torch, self.api = torch, api
+        self.shifts, self.kernel, self.f, self.step, self.prec = [tuple(map(float, s)) for s in shifts_yx], np.asarray(kernel, dtype=np.float64), int(factor), float(step), precision
+        self.dtype = torch.float32 if precision == "f32" else torch.float64
+
+    def load(self, a):  # host array (or tensor) -> device tensor of the working precision
+        t = a if isinstance(a, self.torch.Tensor) else self.torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device="cuda", dtype=self.dtype).contiguous()
+
+    def iterate(self, lr_sub, hr_sub, n):
+        hr, _ = self.api.ibp_batched(lr_sub[None], self.shifts, self.kernel, hr_sub[None], self.f, n, self.step, precision=self.prec,
+                                     want_errors=False)
+        return hr[0]
+
+    def sse_rows(self, lr_sub, hr_sub, lo, hi):
+        """sum over frames of sum((lr_k - forward_model(hr, k))^2) over the LR rows [lo, hi) of the sub-image, float64."""
+        tot = 0.0
+        for k, s in enumerate(self.shifts):
+            sim = self.api.forward_model_batched(hr_sub[None], self.kernel, s, self.f, precision=self.prec)[0]
+            e = (lr_sub[k, lo:hi] - sim[lo:hi]).double()
+            tot += float((e * e).sum().item())
+        return tot
+
+    def rows_to_wire(self, t, on_device):  # a block of rows as a contiguous tensor the process group can send
+        t = t.contiguous()
+        return t if on_device else t.cpu()
+
+    def rows_from_wire(self, dst, t):
+        dst.copy_(t.to(dst.device))
+
+    def empty_wire(self, rows, cols, on_device):
+        return self.torch.empty((rows, cols), dtype=self.dtype, device="cuda" if on_device else "cpu")
+
+    def to_host(self, t):
+        return t.double().cpu().numpy()
+
+
+def _group_info(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(group), dist.get_world_size(group), dist.get_backend(group)
+    return None, 0, 1, None
+
+
+def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, *, engine=None, precision="f32", halo_rows=None,
+                  iters_per_exchange=1, want_errors=True, group=None):
+    """IBP of ONE image on all ranks of the process group.  Every rank passes the same full arrays lr [N, h, w] and hr_init [H, W]
+    (host); each iterates on its own row band.  Returns (band, errors, (a, b)): the rank's owned rows [a, b) of the result as a
+    float64 numpy array, and the complete MSE trace (list of n_iter floats, identical on every rank; None if not wanted).
+    `gather_rows` assembles the image.  With want_errors the rounds are run one iteration per call so that the trace can be taken
+    before every update, as the reference does; the exchange still happens every `iters_per_exchange` iterations."""
+    dist, rank, world, backend = _group_info(group)
+    lr = np.asarray(lr) if not hasattr(lr, "shape") else lr
+    N, h, w = lr.shape
+    H, W = hr_init.shape
+    f = int(factor)
+    if (H, W) != (h * f, w * f):
+        raise ValueError("row-band mode needs hr_init of exactly factor x the LR shape")
+    m = int(iters_per_exchange)
+    if m < 1:
+        raise ValueError("iters_per_exchange must be >= 1")
+    eng = engine or GpuEngine(shifts_yx, kernel, f, step, precision)
+    if halo_rows is None:
+        halo_rows = m * reach_rows(f, shifts_yx, np.asarray(kernel).shape[0], getattr(eng, "prec", precision))
+    a, b, A, B = band_plan(h, f, world, halo_rows)[rank]
+    lr_sub = eng.load(lr[:, A // f:B // f])
+    hr_sub = eng.load(hr_init[A:B])
+    on_dev = backend is not None and "nccl" in backend  # CUDA tensors travel over RCCL; a gloo-only group gets host copies
+    up, dn = (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
+    sse = np.zeros(n_iter, dtype=np.float64)
+
+    def exchange():
+        # my first / last `halo_rows` own rows go to the neighbour whose halo they are; its own rows fill my halo
+        ops, recvs = [], []
+        for nb, own_lo, halo_lo in ((up, a - A, a - A - halo_rows), (dn, b - A - halo_rows, b - A)):
+            if nb is None:
+                continue
+            send = eng.rows_to_wire(hr_sub[own_lo:own_lo + halo_rows], on_dev)
+            recv = eng.empty_wire(halo_rows, W, on_dev)
+            ops += [dist.P2POp(dist.isend, send, nb, group), dist.P2POp(dist.irecv, recv, nb, group)]
+            recvs.append((halo_lo, recv))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        for halo_lo, recv in recvs:
+            eng.rows_from_wire(hr_sub[halo_lo:halo_lo + halo_rows], recv)
+
+    it = 0
+    while it < n_iter:
+        n = min(m, n_iter - it)
+        if want_errors:
+            for j in range(n):
+                sse[it + j] = eng.sse_rows(lr_sub, hr_sub, (a - A) // f, (b - A) // f)
+                hr_sub = eng.iterate(lr_sub, hr_sub, 1)
+        else:
+            hr_sub = eng.iterate(lr_sub, hr_sub, n)
+        it += n
+        if world > 1 and it < n_iter:
+            exchange()
+    errors = None
+    if want_errors:
+        if world > 1:
+            import torch
+            t = torch.from_numpy(sse)
+            t = t if "gloo" in backend else t.cuda()  # a host vector wherever the group has a host backend
+            dist.all_reduce(t, group=group)  # the one collective of the call: completes the trace
+            sse = t.cpu().numpy()
+        errors = [float(v) / (N * h * w) for v in sse]
+    return eng.to_host(hr_sub[a - A:b - A]), errors, (a, b)
+
+
+def gather_rows(band, bounds, H, dst=0, group=None):
+    """The whole image on rank `dst` (None elsewhere) from every rank's owned rows; host-side, for writing the result out."""
+    dist, rank, world, _ = _group_info(group)
+    if world == 1:
+        return np.asarray(band)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object((bounds, np.asarray(band)), parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = np.empty((H, band.shape[1]), dtype=np.float64)
+    seen = 0
+    for (lo, hi), rows in parts:
+        out[lo:hi] = rows
+        seen += hi - lo
+    if seen != H:
+        raise RuntimeError("row bands do not tile the image")
+    return out

@@ -9,6 +9,8 @@ Several GPUs: launch it under torchrun, one process per GPU --
 Session i goes to rank i mod G (the reference's outer loop order, mono_cal_target/run_sr.py:358-360); the ranks share nothing
 but the output directory, so there is no collective on the data path, only a barrier before rank 0 reports the total time.
 RANK / LOCAL_RANK / WORLD_SIZE are read, and the device chosen, BEFORE the first GPU call.
+--row-bands (cal_target kinds) is the other mode: every rank walks all sessions and each image's IBP loop is split into row bands
+whose halo rows travel point to point between neighbouring ranks (sr_mi355x/rowband.py; RCCL send/recv on the GPUs).
 """
 import argparse
 import os
@@ -29,6 +31,8 @@ def main(argv=None):
     ap.add_argument("--metrics", action="store_true",
                     help="mono_cal_target only: also write metrics.json (slanted-edge MTF50/MTF10, bar contrast: the "
                          "summary of the reference's analysis.ipynb) next to the PNGs")
+    ap.add_argument("--row-bands", action="store_true",
+                    help="several GPUs on ONE image: split every image's IBP loop into row bands (cal_target kinds; under torchrun)")
     args = ap.parse_args(argv)
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -37,7 +41,8 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(0 if os.environ.get("SRX_ONE_GPU") else local_rank)  # SRX_ONE_GPU: rehearsal of the N > 1 path on a one-GPU box
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")  # a barrier and nothing else: the data path has no collective
+        # item sharding: a barrier and nothing else (gloo).  Row bands: halo rows as CUDA tensors over RCCL, host objects over gloo
+        dist.init_process_group("cpu:gloo,cuda:nccl" if args.row_bands and not os.environ.get("SRX_ONE_GPU") else "gloo")
     api.set_precision(args.precision)
     if args.psf == "measured":
         if not args.psf_dir:
@@ -51,7 +56,8 @@ def main(argv=None):
     print(f"Found {len(sessions)} session(s):\n" + "\n".join(f"  {os.path.basename(s)}" for s in sessions))
     t0 = time.time()
     metrics_cb = session.write_metrics if (args.metrics and args.kind == "mono_cal_target") else None
-    session.process_sessions(sessions, psf, args.output_dir, args.kind, rank=rank, world=world, on_written=metrics_cb)
+    session.process_sessions(sessions, psf, args.output_dir, args.kind, rank=rank, world=world, on_written=metrics_cb,
+                             row_bands=args.row_bands and world > 1)
     if dist is not None:
         dist.barrier()
     if rank == 0:

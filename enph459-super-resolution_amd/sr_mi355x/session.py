@@ -137,9 +137,11 @@ def load_corner_reps(session_dir, red):
     return all_reps, list(CORNER_SHIFTS)
 
 
-def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step=IBP_STEP_SIZE):
+def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step=IBP_STEP_SIZE, row_bands=False):
     """Native-2x, SAA and SAA+IBP of one frame set, all on the device (run_sr.py:274-292).
-    -> dict of float device tensors + the MSE trace."""
+    -> dict of float device tensors + the MSE trace.
+    row_bands: every rank of the process group calls this with the same frames; the IBP loop runs on row bands of the ONE image
+    (rowband.ibp_row_bands: halo rows exchanged point to point), and only rank 0 gets "SAA_IBP" (None elsewhere)."""
     import torch
     lr64 = torch.stack(frames)
     with _loader_precision():
@@ -147,6 +149,12 @@ def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step
     lr = lr64.to(api._TORCH_DT[api.get_precision()])
     native = api.zoom_batched(mean_lr[None], factor)[0]
     saa = api.shift_and_add_batched(lr[None], shifts, factor)
+    if row_bands:
+        from . import rowband
+        band, errs, bounds = rowband.ibp_row_bands(lr, shifts, psf_kernel, saa[0], factor, n_iter, step, precision=api.get_precision())
+        full = rowband.gather_rows(band, bounds, saa.shape[1])
+        hr0 = None if full is None else torch.from_numpy(full).to(saa)
+        return {"native_2x": native, "SAA": saa[0], "SAA_IBP": hr0, "LR_mean": mean_lr}, errs
     hr, errs = api.ibp_batched(lr[None], shifts, psf_kernel, saa.clone(), factor, n_iter, step)
     return {"native_2x": native, "SAA": saa[0], "SAA_IBP": hr[0], "LR_mean": mean_lr}, [float(e) for e in errs[0].cpu()]
 
@@ -242,11 +250,13 @@ def _save_outputs(out_dir, images, errors, lr_name, extra=None):
     _pending.append(_writer_pool().submit(job))
 
 
-def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None, verbose=True, batch_reps=True, loaded=None, flush=True):
+def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None, verbose=True, batch_reps=True, loaded=None, flush=True,
+                    row_bands=False):
     """Counterpart of process_session / process_combo.  Returns the list of output directories written
     (empty if everything was already done).  batch_reps: the reps of a barcode session that are still to do go through the
     library in one B = reps call (reconstruct_batch) instead of one call per rep; `loaded`: frames already decoded by a
-    Prefetcher (what load_corner_reps / load_mono_cal_session / load_rgb_cal_combo would return)."""
+    Prefetcher (what load_corner_reps / load_mono_cal_session / load_rgb_cal_combo would return).  row_bands (the two cal_target
+    kinds: one large image per session): all ranks work on this one session (reconstruct(row_bands=True)), rank 0 writes."""
     kind = kind or detect_kind(session_dir)
     if kind not in IBP_ITERATIONS:
         raise ValueError("kind must be one of " + ", ".join(IBP_ITERATIONS))
@@ -266,7 +276,9 @@ def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None
             frames, shifts = loaded or load_rgb_cal_combo(session_dir)
             lr_name = "LR_red_mean.png"
             extra = {"shifts.json": {"shifts_lr_yx": [list(s) for s in shifts], "corner_labels": CORNER_ORDER}}
-        images, errors = reconstruct(frames, shifts, psf_kernel, n_iter)
+        images, errors = reconstruct(frames, shifts, psf_kernel, n_iter, row_bands=row_bands)
+        if images["SAA_IBP"] is None:  # row-band mode, not rank 0: the assembled image lives on rank 0
+            return written
         _save_outputs(out_dir, images, errors, lr_name, extra)
         if flush:
             flush_writes()
@@ -306,12 +318,15 @@ def load_session(session_dir, kind):
     return load_corner_reps(session_dir, kind == "rgb_barcodes")
 
 
-def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None):
+def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None, row_bands=False):
     """The reference's outer loop (mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301) over the sessions this
     rank owns (session i -> rank i mod world, parallel.shard_indices: independent items, no collective), with the PNG decode
-    and upload of session k + 1 overlapped with the device work of session k.  -> output directories written by this rank."""
+    and upload of session k + 1 overlapped with the device work of session k.  -> output directories written by this rank.
+    row_bands: the other way to use several GPUs -- every rank walks ALL sessions and each image is split into row bands."""
     from . import parallel
-    mine = [sessions[i] for i in parallel.shard_indices(len(sessions), rank, world)]
+    if row_bands and kind not in ("mono_cal_target", "rgb_cal_target"):
+        raise ValueError("row_bands is for the one-image-per-session kinds (the barcode kinds batch their reps instead)")
+    mine = list(sessions) if row_bands else [sessions[i] for i in parallel.shard_indices(len(sessions), rank, world)]
     say = print if verbose else (lambda *a, **k: None)
     written = []
 
@@ -323,7 +338,8 @@ def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbo
 
     for k, (sdir, loaded) in enumerate(Prefetcher(mine, load), 1):
         say(f"\n[rank {rank}: {k}/{len(mine)}] {os.path.basename(sdir)}")
-        out = process_session(sdir, psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded, flush=on_written is not None)
+        out = process_session(sdir, psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded, flush=on_written is not None,
+                              row_bands=row_bands)
         if on_written:
             for d in out:
                 on_written(d)

@@ -159,3 +159,32 @@ def test_run_sr_two_ranks_on_one_gpu(tmp_path, g_real):
     for sname in ("s0", "s1", "s2"):
         for rep in ("rep0", "rep1"):
             assert _png_bytes(str(tmp_path / "one" / sname / rep)) == _png_bytes(str(tmp_path / "two" / sname / rep))
+
+
+def test_run_sr_row_bands_two_ranks_on_one_gpu(tmp_path, g_real):
+    """`run_sr --row-bands` under torch.distributed.run: both ranks work on the SAME mono_cal_target session, each iterating its row
+    band of the one image (sr_mi355x/rowband.py), rank 0 writes.  Against the single-process run of the same command line."""
+    import subprocess
+    import sys
+    sess = tmp_path / "data" / "cal_target_tall"
+    sess.mkdir(parents=True)
+    tall = np.concatenate([g_real["mono_tl_lr"], g_real["mono_mid_lr"], g_real["mono_br_lr"]], axis=1)  # 5 frames of 144 x 48
+    for (fname, _), frame in zip(session.IMAGE_SHIFTS, tall):
+        Image.fromarray(frame).save(sess / fname)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRX_ONE_GPU="1", PYTHONPATH=os.path.join(root, "enph459-super-resolution_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    args = ["-m", "sr_mi355x.run_sr", "--kind", "mono_cal_target", "--data-dir", str(tmp_path / "data")]
+    one = subprocess.run([sys.executable] + args + ["--output-dir", str(tmp_path / "one")], capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547"] + args + ["--row-bands", "--output-dir", str(tmp_path / "two")], capture_output=True,
+                         text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    d1, d2 = tmp_path / "one" / "cal_target_tall", tmp_path / "two" / "cal_target_tall"
+    for name in ("native_2x.png", "SAA.png", "LR_mean.png"):
+        assert np.array_equal(np.array(Image.open(d1 / name)), np.array(Image.open(d2 / name)))
+    a, b = np.array(Image.open(d1 / "SAA_IBP.png")).astype(np.int16), np.array(Image.open(d2 / "SAA_IBP.png")).astype(np.int16)
+    assert a.shape == (288, 96) and np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.999
+    m1, m2 = (json.load(open(d / "convergence.json"))["ibp_mse"] for d in (d1, d2))
+    np.testing.assert_allclose(m2, m1, rtol=2e-5)
+    assert os.path.exists(d2 / "done.flag")
