@@ -1,28 +1,38 @@
-// srx_ztile.hpp -- delta = 0 IBP iteration on CU-resident 256 x 256 tiles of a large frame, one launch per iteration.
+// srx_ztile.hpp -- delta = 0 IBP iteration on CU-resident tiles of a large frame, ONE launch per iteration.
 //
 // The reference's shipped defaults (all but rgb_cal_target) use nominal +-0.5 px shifts at f = 2: every HR shift is an integer
 // (delta = 0), the spline interpolation condition removes the prefilter, Y is the blurred image itself and the iteration of
 // mono_cal_target/run_sr.py:190-209 is   b = B hr;  G = M - C b (depth-to-space);  hr <- clip(hr + step * B'(G) / N)
 // (srx_mosaic.hpp).  The round-1 kernels ran that as two launches over 32 x 64 / 64 x 64 tiles with the G plane in HBM
 // (27 B per HR pixel against 13 algorithmic, 0.25 of the HBM roofline on a 3072 x 4096 frame).  Here one workgroup keeps a
-// 256 x 256 region in registers through the whole chain -- the machinery of srx_patch.hpp (64 x 64 blocks, column / row
-// layouts, wave-private LDS transposes, halo exchange through LDS) minus the recursions -- and writes the 244 x 244 pixels
-// whose 6-pixel dependency cone (3 for B, 3 for B') lies inside the region: 1.10x recompute, no intermediate plane.
+// 64 x 256 region in registers through the whole chain -- the machinery of srx_patch.hpp (64 x 64 blocks, column / row
+// layouts, wave-private LDS transposes, halo exchange through LDS) minus the recursions -- and writes the 52 x 244 pixels
+// whose 6-pixel dependency cone (3 for B, 3 for B') lies inside the region: 1.29x recompute, no intermediate plane.
 //
-// 512 threads = 8 waves, each owning 64 rows x 128 columns (two 64 x 64 blocks): with 256 registers per lane the 128-value
-// working plane, the 134-value blur window and the prefetched operands fit without spills (the 1024-thread / 128-register
-// layout of srx_patch.hpp spills ~150 values per iteration).
+// Tile shape (measured on one 3072 x 4096 frame / on eight): 256 threads = 4 waves side by side, 64 rows (NSY = 1), 33.9 KB of
+// LDS.  With the pre-update state re-read for the update: 152 registers, three tiles per CU, 245 MB of HBM traffic per iteration
+// (PMC; 5.1 TB/s -- the kernel was bound by its own traffic), 48.4 / 301 us.  With the state HELD in 64 more registers
+// (SRX_ZTILE_HOLD, the default): 216 registers, two tiles per CU, 180 MB, 43.9 / 268 us.  Taller tiles recompute less but run
+// slower: NSY = 2 (128 rows, 512 threads) 50 / 322 us, NSY = 4 (256 x 256, 1024 threads, one tile per CU) 64 / 446 us -- several
+// small independent workgroups per CU overlap one tile's memory phases with another's arithmetic, one lock-step workgroup
+// cannot.  Four tiles per CU (128 registers) spill 107 values: 61 / 452 us.
 //
 // Near band (LR row / column 0 replicated into SciPy's pad: pixels g < -n_min, in the first rows / columns of the IMAGE): tiles
 // on the top / left image edge evaluate the per-pixel lists of k_build_near from two LDS strips of b, as k_ibp_patch does.
-// The state ping-pongs between two buffers (a tile reads its neighbours' pixels of the previous iteration).
+// The state ping-pongs between two zero-padded planes (a tile reads its neighbours' pixels of the previous iteration); M and C
+// travel as one packed 16-bit operand per pixel when the samples are 8-bit integers (k_ztile_pack).
 #pragma once
 #include "srx_patch.hpp"
 #ifndef SRX_ZTILE_NSY
 #define SRX_ZTILE_NSY 1
 #endif
+#ifndef SRX_ZTILE_HOLD
+#define SRX_ZTILE_HOLD 1  // the pre-update state stays in 64 more registers (216 in all: two tiles per CU) instead of being read again
+                          // for the update: 245 -> 180 MB of HBM traffic per iteration of a 3072 x 4096 frame, 48.4 -> 43.9 us (eight
+                          // frames 301 -> 268 us).  0: re-read, 152 registers, three tiles per CU.
+#endif
 #ifndef SRX_ZTILE_WPE
-#define SRX_ZTILE_WPE 3  // waves per SIMD the kernel is compiled for: 3 tiles of 4 waves per CU (170 registers), 4 would be 128
+#define SRX_ZTILE_WPE (SRX_ZTILE_HOLD ? 2 : 3)  // waves per SIMD the kernel is compiled for = tiles per CU (4 waves per tile)
 #endif
 
 namespace srx {
@@ -35,16 +45,14 @@ using patch::TSD;
 constexpr int RG = 256;           // region width (and the stride of the strips)
 constexpr int HALO = 6;           // 3 (blur) + 3 (adjoint blur)
 constexpr int VT = RG - 2 * HALO; // 244 valid columns per tile
-constexpr int NSY = SRX_ZTILE_NSY;            // block rows per tile: region height 64 NSY.  Two (512 threads, 80 KB of LDS) lets TWO tiles share
-                                  // a CU, so one tile's memory phases overlap the other's arithmetic: a lone 256 x 256 tile per CU
-                                  // (NSY = 4) spends ~35 us of its ~90 us moving its own 0.9 MB through one CU's memory pipe
+constexpr int NSY = SRX_ZTILE_NSY;  // block rows per tile: region height 64 NSY (1: see the header for what 2 and 4 measured)
 constexpr int RGY = 64 * NSY, VTY = RGY - 2 * HALO;
 constexpr int SW = 4;             // strip pitch (rows of the top strip / columns of the left strip)
 // LDS: 16 wave regions of srx_patch.hpp (transpose image + exchange slots), then the near-band strips
 // The strips are four rows of RG words (top band) / RGY rows of four words (left band).  They live in the parts of the wave regions
 // that neither the exchange slots ([0, 384) and [1024, 1408)) nor anything else uses between the two transposes: row k of the top
 // strips in region k at 384 (Y) and 640 (G), the left strips in regions 0 and 1 at 1408 (RGY * 4 <= 704 words) -- which keeps a
-// one-block-high tile at 33.9 KB, FOUR tiles per CU.
+// one-block-high tile at 33.9 KB (the LDS would admit four tiles per CU; the register file admits three).
 constexpr int YT_OFF = 384, GT_OFF = 640, YL_OFF = 1408, GL_OFF = patch::RW + 1408;
 static_assert(SW <= 4 * NSY && 4 * RGY <= 704 && GT_OFF + RG <= patch::SLOT1 && YT_OFF + RG <= GT_OFF, "strip placement");
 constexpr int OFF_PART = 4 * NSY * patch::RW, LDS_WORDS = OFF_PART + 32;
@@ -241,6 +249,12 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
 #pragma unroll
     for (int i = 0; i < 64; i++)
         a[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+#if SRX_ZTILE_HOLD
+    float hold[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+        hold[i] = a[i];
+#endif
     // blur down the columns (three rows from the blocks above / below; zero at the region's edge: those outputs are outside
     // every dependency cone that ends in a stored pixel)
     SRX_PSTAMP(1);
@@ -428,6 +442,11 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     const int vst = (cc >= HALO && cc < RG - HALO && pc0 + cc - HALO < W) ? vc0 : 0x7ffffff0;
     // loads and arithmetic first, every store at the very end: vmcnt counts loads and stores in one order, so a wait for a batch of
     // loads behind a batch of stores would also wait for those stores to complete
+#if SRX_ZTILE_HOLD
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+        a[i] = __builtin_amdgcn_fmed3f(fmaf(a[i], za.sn, hold[i]), 0.f, 255.f);
+#else
     {
         float hv[16], hw[16];
 #pragma unroll
@@ -448,6 +467,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#endif
     SRX_PSTAMP(11);
 #pragma unroll
     for (int i = 0; i < 64; i++) {

@@ -29,6 +29,8 @@ for wl in c2 c3_mono; do
     timeout -k 10 240 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d "$O/${wl}_sq1" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_sq1.log" 2>&1
     echo "== $wl SQ pass 2"
     timeout -k 10 240 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d "$O/${wl}_sq2" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_sq2.log" 2>&1
+    echo "== $wl TCC request sizes (FETCH_SIZE's own terms: 32 / 64 / 128-byte fabric reads; diagnostic, may fail without harm)"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_BUBBLE_sum --output-format csv -d "$O/${wl}_tcc" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_tcc.log" 2>&1 || echo "   (TCC pass failed)"
 done
 echo "== bench lines"
 cd "$R"
