@@ -203,16 +203,17 @@ __device__ unsigned long long srx_dbg_stamps[5][8][40000];  // [kernel][phase][b
                 srx_dbg_stamps[K][PH][_blk] = _t;                                                                \
         }                                                                                                       \
     } while (0)
-// the patch-resident kernel: lane 0 of EVERY wave (16 per block), first 256 blocks: [phase][block * 16 + wave]
+// lane 0 of EVERY wave of the first blocks (256 blocks of 16 waves, 1024 of 4): [phase][block * waves per block + wave]
 __device__ unsigned long long srx_dbg_pstamps[24][4096];
 #define SRX_PSTAMP(PH)                                                                                         \
     do {                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         const unsigned _lb = blockIdx.x + gridDim.x * blockIdx.y;                                               \
-        if ((threadIdx.x & 63) == 0 && _lb < 256 && blockIdx.z == 0) {                                          \
+        const unsigned _sl = _lb * (blockDim.x >> 6) + (threadIdx.x >> 6);                                      \
+        if ((threadIdx.x & 63) == 0 && _sl < 4096 && blockIdx.z == 0) {                                         \
             unsigned long long _t;                                                                               \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
-            srx_dbg_pstamps[PH][_lb * 16 + (threadIdx.x >> 6)] = _t;                                             \
+            srx_dbg_pstamps[PH][_sl] = _t;                                                                       \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)

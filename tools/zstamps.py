@@ -16,7 +16,7 @@ buf = np.zeros((24, 4096), dtype=np.uint64)
 lib = _lib.load(); lib.srx_debug_pstamps.argtypes = [ctypes.c_void_p]
 assert lib.srx_debug_pstamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 NPH = 13
-t = buf[:NPH].astype(np.int64).reshape(NPH, 256, 16)[:, :, :4]
+t = buf[:NPH].astype(np.int64).reshape(NPH, 1024, 4)
 names = ["load 64 rows", "blur_v", "barrier", "transpose 1", "prefetch + blur_h", "near band (edge tiles)", "G step", "MSE + blur'_h", "barrier + transpose 2", "blur'_v", "update (loads)", "stores"]
 ok = t[0, :, 0] > 0
 t = t[:, ok]
@@ -25,3 +25,13 @@ print(f"{ok.sum()} tiles x 4 waves; cycles first -> last stamp: median {np.media
 for i in range(NPH - 1):
     d = t[i + 1] - t[i]
     print(f"  {names[i]:26s} median {np.median(d):8.0f}  mean {d.mean():8.0f}  max {d.max():8d}  share {100 * d.mean() / tot.mean():5.1f} %")
+
+# timeline of the launch: when tiles start and end, per XCD (workgroup k runs on XCD k mod 8; every XCD has its own clock base)
+st, en = t[0].min(axis=1), t[NPH - 1].max(axis=1)
+for x in range(8):
+    a, b = st[x::8], en[x::8]
+    a0 = a.min()
+    o = np.argsort(a)
+    starts = np.sort(a - a0)
+    print(f"XCD {x}: {len(a)} tiles, span {b.max() - a0:7d} cycles, tile duration median {np.median(b - a):6.0f};  starts: "
+          f"{(starts < 2000).sum()} within 2000 cycles, quartiles {np.percentile(starts, 25):.0f} / {np.percentile(starts, 50):.0f} / {np.percentile(starts, 75):.0f} / {starts.max():.0f}")
