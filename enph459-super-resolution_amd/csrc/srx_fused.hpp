@@ -1252,6 +1252,8 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)  // float: three 
         stash();
         const int cjx0 = jx0, cnpx = npx;
         __syncthreads();
+        if (k == 0)
+            SRX_STAMP(3, 5);
         if (k + 1 < N) {
             geometry(k + 1);
             fetch(k + 1);
@@ -1283,11 +1285,17 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)  // float: three 
             acc0[i] += a0;
             acc1[i] += a1;
             // pin the sums of every row in place: left alone, hipcc hoists the LDS reads of all RPW rows ahead of the
-            // fmas (196 VGPRs, two blocks per CU)
+            // fmas (196 VGPRs, two blocks per CU).  The row-by-row order is not what bounds the loop: rows in groups of two or
+            // eight with all of a group's reads ahead of its fmas ran the same 7 K cycles per frame (tools/stamps.py) -- the 12
+            // waves of a CU read 565 KB of LDS per frame here, 4.4-8.8 K cycles of the LDS itself.  A separable gather (LR rows
+            // first, 3.5x fewer reads) is the way down.
             asm volatile("" : "+v"(acc0[i]), "+v"(acc1[i])::"memory");
         }
+        if (k == 0)
+            SRX_STAMP(3, 6);
         __syncthreads();  // all taps of frame k read: the patch may be overwritten
     }
+    SRX_STAMP(3, 7);
 #pragma unroll
     for (int i = 0; i < RPW; i++) {
         const int rr = uwave + 4 * i;

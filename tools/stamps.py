@@ -44,6 +44,10 @@ for k, (kn, ph) in names.items():
     for i in range(last):
         d = (t[i + 1, :nb] - t[i, :nb])[ok]
         print(f"    {ph[i + 1]:22s} median {np.median(d):8.0f}  mean {d.mean():8.0f}  share of mean {100 * d.mean() / tot.mean():5.1f} %")
+    if k == 3:  # gather sub-phases (stamps 5, 6, 7 lie between 0 and 1)
+        for name, i0, i1 in (("  first patch fetch + stash", 0, 5), ("  frame 0 rows", 5, 6), ("  frames 1..N-1", 6, 7), ("  sums -> LDS + barrier", 7, 1)):
+            d = (t[i1, :nb] - t[i0, :nb])[ok]
+            print(f"    {name:28s} median {np.median(d):8.0f}  mean {d.mean():8.0f}")
     if k == 0:  # fwd: 5 x 5 tiles per item, x fastest -- edge classes (assumes the C2 shape and no XCD remap effect on class sizes)
         d = (t[4, :nb] - t[3, :nb])[ok]
         print(f"    pixel phase percentiles 10/50/75/90/99: {np.percentile(d, [10, 50, 75, 90, 99]).round(0)}")
