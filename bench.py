@@ -127,8 +127,10 @@ def session_e2e(S, synth, n_sessions=2, reps=4, lr_hw=(768, 1024)):
 
 
 def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, allmax=None, profile=True, world=1):
-    """warmup + `steps` timed reconstructions (SAA + IBP) of one workload, inputs resident in HBM; then one extra, untimed step
-    with HIP events around every fused-path launch for the iteration-level roofline:
+    """warmup + `steps` timed reconstructions (SAA + IBP) of one workload, inputs resident in HBM; then the same `steps` again,
+    untimed, with HIP events around every launch of the library (recorded on its launch stream) for the iteration-level roofline
+    -- a pass of its own because two event records per launch cost a path with 150 launches per step a quarter of its throughput,
+    and behind one discarded step because the first profiled step after a pause measured the 12 ms kernel 1.5 ms long:
         frac = (8 + 4 N / f^2) B H W bytes [SURVEY 8d, eb = 4; 2 eb + eb N / f^2 in general]  /  kernel time per iteration  /  8 TB/s
     where the kernel time per iteration = sum over the kernels launched once per iteration of their mean duration, plus
     (duration / n_iter) of a kernel that runs all iterations in one launch (k_ibp_patch)."""
@@ -162,12 +164,16 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
     lib.srx_profile_enable(1)
     one_step()
     torch.cuda.synchronize()
+    lib.srx_profile_enable(1)  # drops the records of that step
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
     eb = 4 if prec == "f32" else 8
-    kernels = {}
+    kernels = {}  # per STEP: launches and total time of every kernel id, averaged over the timed steps
     tot, cnt = ctypes.c_double(), ctypes.c_long()
     for kid in range(lib.srx_profile_kernel_count()):
         if lib.srx_profile_get(kid, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value:
-            kernels[lib.srx_profile_kernel_name(kid).decode()] = {"launches": cnt.value, "total_ms": round(tot.value, 3),
+            kernels[lib.srx_profile_kernel_name(kid).decode()] = {"launches": cnt.value // steps, "total_ms": round(tot.value / steps, 3),
                                                                   "avg_us": round(tot.value / cnt.value * 1e3, 2)}
     lib.srx_profile_enable(0)
     per_iter = {k: v["avg_us"] for k, v in kernels.items() if v["launches"] == n_iter and k != "k_ibp_patch"}
