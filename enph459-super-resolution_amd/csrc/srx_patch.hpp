@@ -29,6 +29,9 @@
 namespace srx {
 namespace patch {
 
+#ifndef SRX_TRANSPOSE_DEF
+#define SRX_TRANSPOSE_DEF 1
+#endif
 #ifndef SRX_PATCH_DBG
 #define SRX_PATCH_DBG 0  // timing ablations of a development build only (results are wrong): 1 no M loads, 2 no hr re-read,
 #endif                   // 4 no near band, 8 no hr park store, 32 / 64 no far / near share of the MSE sum.  Measured (C2, 161 us per
@@ -232,16 +235,26 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
     // Each half of the wave reads its rows in its own pass, so r[] is written under a lane predicate -- and a predicated write
     // keeps the other lanes' previous contents: without a full definition the compiler must treat r[] as live from wherever it was
     // last written, across the whole preceding stage and around the iteration loop (64 registers pinned beside the 64 of the
-    // working plane: ~150 spills per iteration).  So pass 0 reads UNPREDICATED: the upper half-wave re-reads the lower half's
-    // rows (same addresses, no bank conflict), which defines every element exactly where its life should start -- after pass 0
-    // has parked a[0..31], not before (an up-front definition keeps 128 registers live through the first 32 stores).
+    // working plane: ~150 spills per iteration).  An empty asm defines every element, placed where its life should start: after
+    // pass 0 has parked a[0..31] in LDS, not before (an up-front definition keeps 128 registers live through the first 32 stores).
+    // (SRX_TRANSPOSE_DEF 0: pass 0 reads unpredicated instead -- the upper half-wave re-reads the lower half's rows.  Same
+    // registers, but a third more LDS read traffic in a phase the LDS bounds: C2 162 instead of 156 us per iteration.)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int i = 0; i < 32; i++)
             Tw[i * TSD + lane] = a[32 * h + i];
         __builtin_amdgcn_wave_barrier();
+#if SRX_TRANSPOSE_DEF
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                asm volatile("" : "=v"(r[j]));
+        }
+        if ((lane >> 5) == h) {
+#else
         if (h == 0 || (lane >> 5) == h) {
+#endif
             const float2 *row = reinterpret_cast<const float2 *>(Tw + (lane & 31) * TSD);
 #pragma unroll
             for (int k = 0; k < 32; k++) {

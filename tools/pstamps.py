@@ -33,3 +33,19 @@ print(f"k_ibp_patch, last iteration: {nb} blocks x 16 waves; cycles per wave, fi
 for i in range(NPH - 1):
     d = t[i + 1] - t[i]
     print(f"  {names[i]:34s} median {np.median(d):8.0f}   mean {d.mean():8.0f}   min {d.min():7d}  max {d.max():7d}   share {100 * d.mean() / tot.mean():5.1f} %")
+
+# Critical path: a phase that ends in a workgroup barrier lasts until its LAST wave arrives.  T_i = the time the last of the 16 waves
+# passes stamp i; D_i = T_(i+1) - T_i is what the phase costs the iteration (the per-wave medians above smear barrier waits over
+# neighbouring phases).  Also the spread of arrivals at each stamp (last - first wave).
+T = t.max(axis=2)   # [NPH, blocks]
+F = t.min(axis=2)
+print("critical path per phase (last wave to last wave), median over blocks; spread = last - first wave at the phase's end")
+tot_cp = np.median(T[NPH - 1] - T[0])
+for i in range(NPH - 1):
+    if i >= len(names) - 1 and i + 1 != NPH - 1:
+        continue
+    d = T[i + 1] - T[i]
+    sp = T[i + 1] - F[i + 1]
+    nm = names[i] if i < len(names) else f"phase {i}"
+    print(f"  {nm:34s} {np.median(d):8.0f}   spread {np.median(sp):7.0f}   share {100 * np.median(d) / tot_cp:5.1f} %")
+print(f"  total {tot_cp:.0f}")
