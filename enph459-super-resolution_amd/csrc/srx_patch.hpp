@@ -29,6 +29,9 @@
 namespace srx {
 namespace patch {
 
+#ifndef SRX_ADDTID
+#define SRX_ADDTID 1
+#endif
 #ifndef SRX_TRANSPOSE_DEF
 #define SRX_TRANSPOSE_DEF 1
 #endif
@@ -239,11 +242,59 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
     // pass 0 has parked a[0..31] in LDS, not before (an up-front definition keeps 128 registers live through the first 32 stores).
     // (SRX_TRANSPOSE_DEF 0: pass 0 reads unpredicated instead -- the upper half-wave re-reads the lower half's rows.  Same
     // registers, but a third more LDS read traffic in a phase the LDS bounds: C2 162 instead of 156 us per iteration.)
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Tw);  // LDS byte address of the wave's region
+    (void)m0v;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+#if SRX_ADDTID
+        // Tw[i * TSD + lane] = a[32 h + i] as ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address register): two LDS
+        // cycles per wave-instruction, where ds_write_b32 takes four (its address and data registers travel to the LDS at two cycles
+        // per dword) -- the transposes are bound by exactly that (C2: 154 -> 152 us per iteration).  M0 and the stores in one asm block:
+        // the compiler does not model M0 here.  M0 carries the full LDS byte address (the wave regions reach 135 KB; gfx950 honours more
+        // than the 16 bits older ISA documents name -- with the address masked to 16 bits waves 8..15 wrote into the wrong regions and
+        // tests/test_gpu_parity.py::test_patch_kernel_vs_oracle failed at once).
+        static_assert(TSD * 4 == 264, "offsets below");
+        asm volatile("s_mov_b32 m0, %16\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\t"
+                     "ds_write_addtid_b32 %1 offset:264\n\t"
+                     "ds_write_addtid_b32 %2 offset:528\n\t"
+                     "ds_write_addtid_b32 %3 offset:792\n\t"
+                     "ds_write_addtid_b32 %4 offset:1056\n\t"
+                     "ds_write_addtid_b32 %5 offset:1320\n\t"
+                     "ds_write_addtid_b32 %6 offset:1584\n\t"
+                     "ds_write_addtid_b32 %7 offset:1848\n\t"
+                     "ds_write_addtid_b32 %8 offset:2112\n\t"
+                     "ds_write_addtid_b32 %9 offset:2376\n\t"
+                     "ds_write_addtid_b32 %10 offset:2640\n\t"
+                     "ds_write_addtid_b32 %11 offset:2904\n\t"
+                     "ds_write_addtid_b32 %12 offset:3168\n\t"
+                     "ds_write_addtid_b32 %13 offset:3432\n\t"
+                     "ds_write_addtid_b32 %14 offset:3696\n\t"
+                     "ds_write_addtid_b32 %15 offset:3960\n\t"
+                     :: "v"(a[32 * h + 0]), "v"(a[32 * h + 1]), "v"(a[32 * h + 2]), "v"(a[32 * h + 3]), "v"(a[32 * h + 4]), "v"(a[32 * h + 5]), "v"(a[32 * h + 6]), "v"(a[32 * h + 7]), "v"(a[32 * h + 8]), "v"(a[32 * h + 9]), "v"(a[32 * h + 10]), "v"(a[32 * h + 11]), "v"(a[32 * h + 12]), "v"(a[32 * h + 13]), "v"(a[32 * h + 14]), "v"(a[32 * h + 15]), "s"(m0v) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %16\n\t"
+                     "ds_write_addtid_b32 %0 offset:4224\n\t"
+                     "ds_write_addtid_b32 %1 offset:4488\n\t"
+                     "ds_write_addtid_b32 %2 offset:4752\n\t"
+                     "ds_write_addtid_b32 %3 offset:5016\n\t"
+                     "ds_write_addtid_b32 %4 offset:5280\n\t"
+                     "ds_write_addtid_b32 %5 offset:5544\n\t"
+                     "ds_write_addtid_b32 %6 offset:5808\n\t"
+                     "ds_write_addtid_b32 %7 offset:6072\n\t"
+                     "ds_write_addtid_b32 %8 offset:6336\n\t"
+                     "ds_write_addtid_b32 %9 offset:6600\n\t"
+                     "ds_write_addtid_b32 %10 offset:6864\n\t"
+                     "ds_write_addtid_b32 %11 offset:7128\n\t"
+                     "ds_write_addtid_b32 %12 offset:7392\n\t"
+                     "ds_write_addtid_b32 %13 offset:7656\n\t"
+                     "ds_write_addtid_b32 %14 offset:7920\n\t"
+                     "ds_write_addtid_b32 %15 offset:8184\n\t"
+                     :: "v"(a[32 * h + 16]), "v"(a[32 * h + 17]), "v"(a[32 * h + 18]), "v"(a[32 * h + 19]), "v"(a[32 * h + 20]), "v"(a[32 * h + 21]), "v"(a[32 * h + 22]), "v"(a[32 * h + 23]), "v"(a[32 * h + 24]), "v"(a[32 * h + 25]), "v"(a[32 * h + 26]), "v"(a[32 * h + 27]), "v"(a[32 * h + 28]), "v"(a[32 * h + 29]), "v"(a[32 * h + 30]), "v"(a[32 * h + 31]), "s"(m0v) : "memory", "m0");
+#else
 #pragma unroll
         for (int i = 0; i < 32; i++)
             Tw[i * TSD + lane] = a[32 * h + i];
+#endif
         __builtin_amdgcn_wave_barrier();
 #if SRX_TRANSPOSE_DEF
         if (h == 0) {
@@ -773,9 +824,11 @@ __global__ void __launch_bounds__(1024)
                               for (int i = 0; i < 16; i++)
                                   ld[i] = (SRX_PATCH_DBG & 2) ? 1.f : fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (4 * bq + (i >> 2)) * PN * 16);
                           };
-                          if (q == 0)
+                          if (q == 0) {
+                              SRX_PSTAMP(13);
                               load16(hv, 0), load16(hw, 1);
-                          else if (q == 1)
+                          }
+                          if (q == 1)
                               load16(hv, 2);
                           else if (q == 2)
                               load16(hw, 3);

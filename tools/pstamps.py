@@ -27,7 +27,7 @@ nb = min(B, 256)
 t = buf[:NPH].astype(np.int64).reshape(NPH, 256, 16)[:, :nb]
 names = ["park state + blur_v (1 barrier)", "V-fwd chain (2 barriers)", "rowbuf + barrier", "transpose 1", "prefetch + blur_h (1 barrier)",
          "H-fwd chain (2 barriers)", "strips + barrier", "near band + barrier", "G = M - C Y", "H-bwd (3 barriers)", "barrier",
-         "transpose 2", "V-bwd (3 barriers)", "update"]
+         "transpose 2", "V-bwd recursions (3 barriers)", "V-blur' + state reload + update"]
 tot = t[NPH - 1] - t[0]
 print(f"k_ibp_patch, last iteration: {nb} blocks x 16 waves; cycles per wave, first -> last stamp: median {np.median(tot):.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f}")
 for i in range(NPH - 1):
@@ -49,3 +49,9 @@ for i in range(NPH - 1):
     nm = names[i] if i < len(names) else f"phase {i}"
     print(f"  {nm:34s} {np.median(d):8.0f}   spread {np.median(sp):7.0f}   share {100 * np.median(d) / tot_cp:5.1f} %")
 print(f"  total {tot_cp:.0f}")
+
+# per wave (s = wave >> 2: block row, u = wave & 3: block column): when each wave passes a stamp, relative to the block's first wave
+for ph in (12, 13, 14):
+    rel = t[ph] - t[ph].min(axis=1, keepdims=True)
+    print(f"stamp {ph}: median arrival per wave after the block's first wave (rows s = 0..3, columns u = 0..3)")
+    print(np.median(rel, axis=0).reshape(4, 4).round(0))
