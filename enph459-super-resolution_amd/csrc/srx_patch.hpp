@@ -392,6 +392,7 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     const float z = PZ;
     const float w0 = wfb[4], w1 = wfb[5], w2 = wfb[6], w3 = wfb[7];
     const float vn = last ? w0 * a[63] : 0.f;  // v'[n]: the one pad sample below the line whose FIR window holds a real row
+    SRX_PSTAMP(15);
     float st = 0.f;
     if (first) {  // the pad: a constant run of G[-ex] (steady state), then the two samples whose window reaches rows 0, 1
         st = (w0 + w1 + w2 + w3) * gtop * K2;
@@ -406,8 +407,10 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
         gprev = g0;
         a[t] = st;
     }
+    SRX_PSTAMP(16);
     Rown[s1 + lane] = a[63];
     __syncthreads();
+    SRX_PSTAMP(17);
     if (!first) {
         const float carry = Rprev[s1 + lane];
 #pragma unroll
@@ -427,7 +430,9 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     Rown[s6 + 192 + lane] = a[61];
     Rown[s6 + 256 + lane] = a[62];
     Rown[s6 + 320 + lane] = a[63];
+    SRX_PSTAMP(18);
     __syncthreads();
+    SRX_PSTAMP(19);
     float e[70];  // the block's coefficients with three on either side (zero outside the image)
     e[0] = e[1] = e[2] = e[67] = e[68] = e[69] = 0.f;
     if (!last) {
@@ -445,6 +450,7 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
 #pragma unroll
     for (int i = 0; i < 64; i++)
         e[3 + i] = a[i];
+    SRX_PSTAMP(20);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         mid(q);  // caller's hook before every quarter of the blur (loads / stores to overlap with it)

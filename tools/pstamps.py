@@ -55,3 +55,12 @@ for ph in (12, 13, 14):
     rel = t[ph] - t[ph].min(axis=1, keepdims=True)
     print(f"stamp {ph}: median arrival per wave after the block's first wave (rows s = 0..3, columns u = 0..3)")
     print(np.median(rel, axis=0).reshape(4, 4).round(0))
+
+# inside the LAST backward chain of the iteration (V-bwd; the H-bwd chain writes the same stamps earlier and is overwritten)
+tt = buf[:24].astype(np.int64).reshape(24, 256, 16)[:, :nb]
+Tm = tt.max(axis=2)
+nm = {12: "T2 end -> chain entry", 15: "causal recursion + FIR'", 16: "carry store + barrier", 17: "fix-up + anticausal + 6 stores", 18: "barrier", 19: "halo reads + e[]", 20: "-> first quarter hook"}
+seq = [12, 15, 16, 17, 18, 19, 20, 13]
+print("V-bwd chain, critical path (last wave to last wave):")
+for a_, b_ in zip(seq, seq[1:]):
+    print(f"  {nm[a_]:34s} {np.median(Tm[b_] - Tm[a_]):8.0f}    per-wave median {np.median(tt[b_] - tt[a_]):8.0f}")
