@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(256)
 // own (or outside the image) goes to the plane's trash row / out of the buffer's range.
 // =========================================================================================================================
 __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
-    k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart)
+    k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart,
+                const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
 {
     __shared__ float lds[LDS_WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -242,6 +243,15 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     const __amdgpu_buffer_rsrc_t rs_dst = fused::plane_rsrc(hr_dst + (size_t)b * splane, splane);
     const bool top = ty == 0, left = tx == 0;  // block-uniform: tiles holding the near band
 
+    // The MSE trace of the PREVIOUS iteration: its tiles' partial sums, added up in a fixed order by one interior tile of this
+    // launch (a launch of its own per iteration cost 4.7 us + a gap on a 40 us kernel).  The last iteration's is k_ztile_trace's.
+    if (eprev && tx == min(1, za.tiles_x - 1) && ty == min(1, za.tiles_y - 1)) {
+        static_assert(NSY == 1, "err_trace_reduce is written for 256 threads");
+        double *out = err_prev + (size_t)b * err_stride;
+        err_trace_reduce(eprev, za.tiles_x * za.tiles_y, b, Vtot[b], out, tid, part);
+        if (tid == 0)
+            *out *= scale;
+    }
     SRX_PSTAMP(0);
     // ================= stage A: column layout.  a[i] = region (row 64 s + i, column 64 u + lane) =================
     float a[64], r[64];
@@ -554,11 +564,13 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
         const float *src = (it & 1) ? s1 : s0;
         float *dst = (it & 1) ? s0 : s1;
         double *ep = errors ? ((it & 1) ? ep1 : ep0) : nullptr;
-        SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep);
-        if (errors) {
-            hipLaunchKernelGGL(k_ztile_trace, dim3(B), dim3(256), 0, st, ep, ntiles, Vtot, scale, errors + it, n_iter);
-            SRX_CHECK_LAUNCH();
-        }
+        const double *eprev = errors && it > 0 ? ((it & 1) ? ep0 : ep1) : nullptr;  // the partial sums iteration it - 1 left
+        SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale, errors ? errors + it - 1 : nullptr,
+                   n_iter);
+    }
+    if (errors) {
+        hipLaunchKernelGGL(k_ztile_trace, dim3(B), dim3(256), 0, st, ((n_iter - 1) & 1) ? ep1 : ep0, ntiles, Vtot, scale, errors + n_iter - 1, n_iter);
+        SRX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_ztile_copy_out, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, (n_iter & 1) ? s1 : s0, H, W, HP, WP, hr);
     SRX_CHECK_LAUNCH();

@@ -20,7 +20,8 @@ SQ1="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_IN
 SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
 for wl in c2 c3_mono; do
     echo "== $wl kernel stats"
-    timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${wl}_stats" -o run -- python3 "$R/bench.py" --workload $wl --warmup 1 $COMMON > "$O/${wl}_stats.log" 2>&1
+    # (six calls: the first call after a pause runs the long kernels ~8 % slow, which a two-call average would show)
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${wl}_stats" -o run -- python3 "$R/bench.py" --workload $wl --warmup 2 --steps 4 --no-cpu-baseline --no-roofline --no-secondary > "$O/${wl}_stats.log" 2>&1
     echo "== $wl FETCH_SIZE"
     timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/${wl}_fetch" -o run -- python3 "$R/bench.py" --workload $wl --warmup 0 $COMMON > "$O/${wl}_fetch.log" 2>&1
     echo "== $wl WRITE_SIZE"
