@@ -197,6 +197,20 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
     return out
 
 
+def pmc_traffic(wname, B, prec, it):
+    """HBM bytes per iteration of a workload's iteration kernels from the committed PMC passes (profiles/traffic.json, written by
+    tools/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command line), and their ratio to the
+    algorithmic bytes; (None, None) when that workload / batch / precision was not profiled or a kernel of it is missing."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tf):
+        return None, None
+    tj = json.load(open(tf)).get("workloads", {}).get(f"{wname}:B={B}:{prec}")
+    if not tj or not all(k in tj["kernels"] for k in it["kernels"]):
+        return None, None
+    tr = sum(tj["kernels"][k]["hbm_bytes_per_iteration"] for k in it["kernels"])
+    return (tr, round(tr / it["algorithmic_bytes"], 3)) if tr else (None, None)
+
+
 def cpu_baseline(synth, f, lr_hw, shifts, psf, n_iter, step):
     """The oracle (a CPU port of the reference's algorithm, float64) on a BOUNDED sample of the workload: one
     patch of at most 128x128 LR pixels, full SAA + IBP(n_iter), 1 thread like the reference (scipy.ndimage and
@@ -307,14 +321,7 @@ def main():
                     "dominant_kernel": m.get("dominant"),
                     "note": "achieved = (8 + 4N/f^2) B per HR pixel and iteration (SURVEY 8d) x B H W / kernel time per iteration "
                             "(HIP events on the launch stream); traffic = PMC bytes of the iteration kernels per iteration"}
-        tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (tools/collect_traffic.py)
-        if os.path.exists(tf):
-            tj = json.load(open(tf)).get("workloads", {}).get(f"{args.workload}:B={B}:{prec}")
-            if tj:
-                tr = sum(tj["kernels"][k]["hbm_bytes_per_iteration"] for k in it["kernels"] if k in tj["kernels"])
-                if tr and all(k in tj["kernels"] for k in it["kernels"]):
-                    roofline["traffic"] = tr
-                    roofline["traffic_ratio"] = round(tr / it["algorithmic_bytes"], 3)
+        roofline["traffic"], roofline["traffic_ratio"] = pmc_traffic(args.workload, B, prec, it)
 
     # ---- secondary legs, timed in this same run (rank 0, N = 1): the reference's precision and its own full-frame shapes ----
     legs = None
@@ -327,6 +334,8 @@ def main():
             legs[tag] = {"workload": r["desc"], "dtype": lprec, "batch": r["B"], "n_iter": r["n_iter"], "path": r["path"],
                          "value": round(r["value"], 2), "unit": "HR-MP/s", "ms_per_step": round(r["ms_per_step"], 3), "sane": r["sane"],
                          "iteration": r.get("iteration")}
+            if r.get("iteration"):
+                legs[tag]["iteration"]["traffic"], legs[tag]["iteration"]["traffic_ratio"] = pmc_traffic(wname, r["B"], lprec, r["iteration"])
             del r
             torch.cuda.empty_cache()
         S.set_precision(prec)

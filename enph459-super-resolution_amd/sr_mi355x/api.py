@@ -22,6 +22,7 @@ memory + streams); every FLOP runs in libsrx.so, and there is no CPU fallback.
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -30,21 +31,42 @@ from . import _lib
 from ._lib import (FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME, FLAG_TILES, FLAG_DIAG_NO_ZERO_FUSE,  # noqa: F401  (re-exported)
                    FLAG_DIAG_NO_SEPARABLE, FLAG_DIAG_NO_PREFILTER_TILE, FLAG_DIAG_V1)
 
-_PRECISION = os.environ.get("SRX_PRECISION", "f32")
 _TORCH_DT = {"f32": torch.float32, "f64": torch.float64}
 _ELEM = {"f32": 4, "f64": 8}
+# The working precision is a per-THREAD setting with a process-wide default: the session driver's loader thread works in float64
+# (precision_override) while the main thread reconstructs in float32, and neither may see the other's choice.
+_DEFAULT_PRECISION = "f32"
+_tls = threading.local()
 
 
 def set_precision(p):
-    """'f32' or 'f64': element type of every device buffer and of the arithmetic."""
-    global _PRECISION
+    """'f32' or 'f64': element type of every device buffer and of the arithmetic.  Sets the process default (what every thread
+    uses unless it is inside a precision_override) and drops the calling thread's override, if any."""
+    global _DEFAULT_PRECISION
     if p not in _TORCH_DT:
         raise ValueError("precision must be 'f32' or 'f64'")
-    _PRECISION = p
+    _DEFAULT_PRECISION = p
+    _tls.p = None
 
 
 def get_precision():
-    return _PRECISION
+    return getattr(_tls, "p", None) or _DEFAULT_PRECISION
+
+
+class precision_override:
+    """with precision_override('f64'): ... -- the calling thread's precision inside the block, other threads untouched."""
+
+    def __init__(self, p):
+        if p not in _TORCH_DT:
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.p = p
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "p", None)
+        _tls.p = self.p
+
+    def __exit__(self, *exc):
+        _tls.p = self.prev
 
 
 def _device():
@@ -109,7 +131,7 @@ def last_path():
 # batched primitives: tensors [B, ...] on the device
 # ------------------------------------------------------------------------------------------
 def blur_batched(img, kernel, precision=None):
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(img, prec)
     B, H, W = x.shape
     k, kp = _host_f64(kernel)
@@ -119,7 +141,7 @@ def blur_batched(img, kernel, precision=None):
 
 
 def shift_batched(img, shift_yx, precision=None):
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(img, prec)
     B, H, W = x.shape
     out = torch.empty_like(x)
@@ -130,7 +152,7 @@ def shift_batched(img, shift_yx, precision=None):
 
 
 def zoom_batched(img, factor, precision=None):
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(img, prec)
     B, h, w = x.shape
     f = int(factor)
@@ -143,7 +165,7 @@ def zoom_batched(img, factor, precision=None):
 
 
 def forward_model_batched(hr, kernel, shift_yx, factor, precision=None):
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(hr, prec)
     B, H, W = x.shape
     f = int(factor)
@@ -156,7 +178,7 @@ def forward_model_batched(hr, kernel, shift_yx, factor, precision=None):
 
 
 def back_project_batched(error_lr, kernel, shift_yx, factor, hr_shape, precision=None):
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     e, _ = _to_dev(error_lr, prec)
     B, eh, ew = e.shape
     H, W = int(hr_shape[0]), int(hr_shape[1])
@@ -171,7 +193,7 @@ def back_project_batched(error_lr, kernel, shift_yx, factor, hr_shape, precision
 
 def shift_and_add_batched(lr, shifts_yx, factor=2, precision=None, flags=FLAG_AUTO):
     """lr [B, N, h, w] -> [B, h*f, w*f]."""
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(lr, prec)
     B, N, h, w = x.shape
     f = int(factor)
@@ -185,7 +207,7 @@ def shift_and_add_batched(lr, shifts_yx, factor=2, precision=None, flags=FLAG_AU
 def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, precision=None, flags=FLAG_AUTO,
                 want_errors=True, out=None):
     """lr [B, N, h, w], hr_init [B, H, W] -> (hr [B, H, W], errors float64 [B, n_iter] or None)."""
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     x, _ = _to_dev(lr, prec)
     h0, _ = _to_dev(hr_init, prec)
     B, N, h, w = x.shape
@@ -212,45 +234,45 @@ def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, p
 # the reference's call surface (single image; numpy or torch)
 # ------------------------------------------------------------------------------------------
 def blur(img, kernel):
-    x, was_np = _to_dev(img, _PRECISION)
+    x, was_np = _to_dev(img, get_precision())
     return _out(blur_batched(x[None], kernel)[0], was_np)
 
 
 def ndi_shift(img, shift, order=3, mode="nearest"):
     if order != 3 or mode != "nearest":
         raise NotImplementedError("only order=3, mode='nearest' (the reference's call) is provided")
-    x, was_np = _to_dev(img, _PRECISION)
+    x, was_np = _to_dev(img, get_precision())
     return _out(shift_batched(x[None], shift)[0], was_np)
 
 
 def ndi_zoom(img, zoom, order=3):
     if order != 3:
         raise NotImplementedError("only order=3 (the reference's call) is provided")
-    x, was_np = _to_dev(img, _PRECISION)
+    x, was_np = _to_dev(img, get_precision())
     return _out(zoom_batched(x[None], zoom)[0], was_np)
 
 
 def forward_model(hr, kernel, shift_yx, factor):
-    x, was_np = _to_dev(hr, _PRECISION)
+    x, was_np = _to_dev(hr, get_precision())
     return _out(forward_model_batched(x[None], kernel, shift_yx, factor)[0], was_np)
 
 
 def back_project(error_lr, kernel, shift_yx, factor, hr_shape):
-    x, was_np = _to_dev(error_lr, _PRECISION)
+    x, was_np = _to_dev(error_lr, get_precision())
     return _out(back_project_batched(x[None], kernel, shift_yx, factor, hr_shape)[0], was_np)
 
 
 def shift_and_add(lr_list, shifts_yx, factor=2, order=3):
     if order != 3:
         raise NotImplementedError("only order=3 (the reference's call) is provided")
-    x, was_np = _stack_dev(lr_list, _PRECISION)
+    x, was_np = _stack_dev(lr_list, get_precision())
     return _out(shift_and_add_batched(x[None], shifts_yx, factor)[0], was_np)
 
 
 def ibp(lr_list, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, verbose=True):
     """Returns (hr, errors) like run_sr.py:190-209; `errors` is a list of n_iter floats."""
-    x, was_np = _stack_dev(lr_list, _PRECISION)
-    h0, was_np_h = _to_dev(hr_init, _PRECISION)
+    x, was_np = _stack_dev(lr_list, get_precision())
+    h0, was_np_h = _to_dev(hr_init, get_precision())
     hr, errs = ibp_batched(x[None], shifts_yx, kernel, h0[None], factor, n_iter, step)
     errors = [float(e) for e in errs[0].cpu().numpy()]
     if verbose:  # the reference prints the running MSE every 10 iterations (:207-208)
@@ -264,10 +286,10 @@ def ibp(lr_list, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, verb
 # ------------------------------------------------------------------------------------------
 def decimate(img, f, py=0, px=0):
     """img[py::f, px::f] (run_sr.py:165)."""
-    x, was_np = _to_dev(img, _PRECISION)
+    x, was_np = _to_dev(img, get_precision())
     H, W = x.shape
     out = torch.empty((-(-(H - py) // f), -(-(W - px) // f)), dtype=x.dtype, device=x.device)
-    _lib.check(_fn("srx_decimate", _PRECISION)(_p(x), 1, H, W, int(f), int(py), int(px), _p(out), _stream()),
+    _lib.check(_fn("srx_decimate", get_precision())(_p(x), 1, H, W, int(f), int(py), int(px), _p(out), _stream()),
                "srx_decimate")
     return _out(out, was_np)
 
@@ -279,46 +301,46 @@ def extract_red(img):
 
 def zero_insert(err, f, hr_shape):
     """up = zeros(hr_shape); up[::f, ::f] = err (pad/crop) (run_sr.py:170-175)."""
-    x, was_np = _to_dev(err, _PRECISION)
+    x, was_np = _to_dev(err, get_precision())
     eh, ew = x.shape
     H, W = int(hr_shape[0]), int(hr_shape[1])
     out = torch.empty((H, W), dtype=x.dtype, device=x.device)
-    _lib.check(_fn("srx_zero_insert", _PRECISION)(_p(x), 1, eh, ew, int(f), H, W, _p(out), _stream()),
+    _lib.check(_fn("srx_zero_insert", get_precision())(_p(x), 1, eh, ew, int(f), H, W, _p(out), _stream()),
                "srx_zero_insert")
     return _out(out, was_np)
 
 
 def mean_frames(stack):
     """np.mean(stack, axis=0) (run_sr.py:274; rgb_cal_target/run_sr.py:107-108)."""
-    x, was_np = _stack_dev(stack, _PRECISION)
+    x, was_np = _stack_dev(stack, get_precision())
     R = x.shape[0]
     n = x[0].numel()
     out = torch.empty(x.shape[1:], dtype=x.dtype, device=x.device)
-    _lib.check(_fn("srx_mean_frames", _PRECISION)(_p(x), 1, R, n, _p(out), _stream()), "srx_mean_frames")
+    _lib.check(_fn("srx_mean_frames", get_precision())(_p(x), 1, R, n, _p(out), _stream()), "srx_mean_frames")
     return _out(out, was_np)
 
 
 def mean_frames_batched(stacks):
     """[B, R, ...] -> [B, ...]: np.mean(axis=0) of every item's stack in one call."""
-    x, was_np = _to_dev(stacks, _PRECISION)
+    x, was_np = _to_dev(stacks, get_precision())
     B, R = x.shape[0], x.shape[1]
     n = x[0, 0].numel()
     out = torch.empty((B,) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-    _lib.check(_fn("srx_mean_frames", _PRECISION)(_p(x), B, R, n, _p(out), _stream()), "srx_mean_frames")
+    _lib.check(_fn("srx_mean_frames", get_precision())(_p(x), B, R, n, _p(out), _stream()), "srx_mean_frames")
     return _out(out, was_np)
 
 
 def quantize_u8(img):
     """np.clip(img, 0, 255).astype(np.uint8): clamp, then truncate (run_sr.py:303)."""
-    x, was_np = _to_dev(img, _PRECISION)
+    x, was_np = _to_dev(img, get_precision())
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    _lib.check(_fn("srx_quantize_u8", _PRECISION)(_p(x), x.numel(), _p(out), _stream()), "srx_quantize_u8")
+    _lib.check(_fn("srx_quantize_u8", get_precision())(_p(x), x.numel(), _p(out), _stream()), "srx_quantize_u8")
     return out.cpu().numpy() if was_np else out
 
 
 def u8_to_float(img_u8, precision=None):
     """uint8 frame -> float on the device (load_gray's cast, run_sr.py:73-75)."""
-    prec = precision or _PRECISION
+    prec = precision or get_precision()
     t = img_u8 if isinstance(img_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_u8))
     t = t.to(device=_device(), dtype=torch.uint8).contiguous()
     out = torch.empty(t.shape, dtype=_TORCH_DT[prec], device=t.device)

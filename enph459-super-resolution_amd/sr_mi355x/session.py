@@ -51,21 +51,35 @@ LOADER_PRECISION = "f64"  # uint8 -> float, Bayer extraction and the rep / frame
 #                           of k/5 values rounded to float32 flips the truncating uint8 quantiser on ~0.5 % of pixels.
 
 
-class _loader_precision:
-    def __enter__(self):
-        self.prev = api.get_precision()
-        api.set_precision(LOADER_PRECISION)
-
-    def __exit__(self, *exc):
-        api.set_precision(self.prev)
+def _loader_precision():
+    """The loaders' arithmetic in LOADER_PRECISION on the calling thread only (the Prefetcher's thread decodes the next session
+    while the main thread reconstructs the current one in its own precision)."""
+    return api.precision_override(LOADER_PRECISION)
 
 
-def load_gray_dev(path):
-    """PNG -> float64 image on the device (load_gray, mono_cal_target/run_sr.py:73-75)."""
-    a = _png_u8(path)
+_decoders = None
+
+
+def _decode_many(paths):
+    """The PNG files of one session decoded side by side (PIL releases the GIL while it inflates): a 16-frame barcode session
+    spent 80 ms in this loop, one file after the other."""
+    global _decoders
+    if _decoders is None:
+        import concurrent.futures
+        _decoders = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+    return list(_decoders.map(_png_u8, paths))
+
+
+def _to_dev_f(a):
     if a.dtype == np.uint8:
         return api.u8_to_float(a, precision=LOADER_PRECISION)
     return api._to_dev(a, LOADER_PRECISION)[0]
+
+
+def load_gray_dev(path, decoded=None):
+    """PNG -> float64 image on the device (load_gray, mono_cal_target/run_sr.py:73-75).  decoded: the file's pixels, if a caller
+    already has them (_decode_many)."""
+    return _to_dev_f(_png_u8(path) if decoded is None else decoded)
 
 
 def detect_kind(session_dir):
@@ -79,13 +93,9 @@ def detect_kind(session_dir):
 
 def load_mono_cal_session(session_dir):
     """mono_cal_target/run_sr.py:78-99 -> (frames on device, shifts)."""
-    frames, shifts = [], []
-    for fname, s in IMAGE_SHIFTS:
-        path = os.path.join(session_dir, fname)
-        if not os.path.exists(path):
-            continue
-        frames.append(load_gray_dev(path))
-        shifts.append(s)
+    present = [(os.path.join(session_dir, fname), s) for fname, s in IMAGE_SHIFTS if os.path.exists(os.path.join(session_dir, fname))]
+    frames = [_to_dev_f(a) for a in _decode_many([p for p, _ in present])]
+    shifts = [s for _, s in present]
     if len(frames) < 2:
         raise FileNotFoundError(f"Need at least 2 images in {session_dir}")
     return frames, shifts
@@ -111,7 +121,7 @@ def load_rgb_cal_combo(combo_dir):
         if not reps:
             raise FileNotFoundError(f"No images for corner{idx} in {combo_dir}")
         with _loader_precision():
-            reds = [api.extract_red(load_gray_dev(os.path.join(combo_dir, r))) for r in reps]
+            reds = [api.extract_red(_to_dev_f(a)) for a in _decode_many([os.path.join(combo_dir, r) for r in reps])]
             frames.append(api.mean_frames(reds))
         shifts.append(get_shift(label))
     return frames, shifts
@@ -123,14 +133,16 @@ def load_corner_reps(session_dir, red):
                           if m})
     if not rep_indices:
         raise FileNotFoundError(f"No corner*_rep*.png files in {session_dir}")
+    paths = [os.path.join(session_dir, f"corner{ci}_rep{ri:02d}.png") for ri in rep_indices for ci in range(4)]
+    for path in paths:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Missing {path}")
+    decoded = _decode_many(paths)
     all_reps = []
-    for ri in rep_indices:
+    for k in range(len(rep_indices)):
         frames = []
         for ci in range(4):
-            path = os.path.join(session_dir, f"corner{ci}_rep{ri:02d}.png")
-            if not os.path.exists(path):
-                raise FileNotFoundError(f"Missing {path}")
-            img = load_gray_dev(path)
+            img = _to_dev_f(decoded[4 * k + ci])
             with _loader_precision():
                 frames.append(api.extract_red(img) if red else img)
         all_reps.append(frames)
