@@ -877,7 +877,8 @@ struct FrameOffsets {
 template <typename T, int F> struct SaaCfg {
     static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3;  // region edge (odd, <= 128)
     static constexpr int PD = (SR + 12) / F + 6;                                          // LR patch edge bound
-    static constexpr int NT = (SR + 1) / 2;                                               // region rows per wave
+    static constexpr int RS = (SR + 3) & ~3;                                              // row pitch of the row-pass image (16-byte reads)
+    static constexpr int NT = (RS / 2 + 3) & ~3;                                          // region columns per half (a multiple of 4)
     static constexpr int PPT = (PD * PD + 255) / 256;                                     // patch elements per thread
 };
 
@@ -893,13 +894,14 @@ __global__ void __launch_bounds__(256)
                T *__restrict__ out)
 {
     using C = SaaCfg<T, F>;
-    constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NT = C::NT, PPT = C::PPT;
+    constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NT = C::NT, PPT = C::PPT, RS = C::RS;
+    constexpr int ROWS0 = (PD * PD + 3) & ~3;  // the row-pass image starts on a 16-byte boundary (for T = float)
     static_assert(SR <= 128, "two 64-lane chunks per axis");
     // LDS: during the frame loop [patch PD*PD | rows PD*SR]; afterwards the SR*SR region
-    constexpr int FRAME_WORDS = PD * PD + PD * SR;
+    constexpr int FRAME_WORDS = ROWS0 + PD * RS;
     constexpr int WORDS = FRAME_WORDS + NT > SR * SR ? FRAME_WORDS + NT : SR * SR;  // discarded lanes read up to NT words past a row
-    __shared__ T lds[WORDS];
-    T *patch = lds, *rows = lds + PD * PD, *reg = lds;
+    __shared__ __attribute__((aligned(16))) T lds[WORDS];
+    T *patch = lds, *rows = lds + ROWS0, *reg = lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = wave & 1, half = wave >> 1;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
@@ -977,7 +979,7 @@ __global__ void __launch_bounds__(256)
             for (int t = 0; t < (PD + 1) / 2; t++) {
                 const int py = half + 2 * t;
                 if (py < npy && ccok)
-                    rows[py * SR + cc] = v[t];
+                    rows[py * RS + cc] = v[t];
             }
         }
         const int cjy0 = jy0;
@@ -990,11 +992,25 @@ __global__ void __launch_bounds__(256)
         }
         // column pass, accumulated over frames: up_k(y(rr), x) = sum_i zy[y].w[i] * rows[idx[i]][x]
         {
-            const T *q0 = rows + (tY.idx[0] - cjy0) * SR + cb, *q1 = rows + (tY.idx[1] - cjy0) * SR + cb,
-                    *q2 = rows + (tY.idx[2] - cjy0) * SR + cb, *q3 = rows + (tY.idx[3] - cjy0) * SR + cb;
+            // four columns per LDS read: rows of pitch 4k from a column 4j, so every quad is 16-byte aligned.  ds_read_b128 moves 256 B
+            // per LDS cycle, ds_read_b32 128, and this pass is bound by the LDS (4 reads per output, 1.2 MB per frame and CU).  (Pairs
+            // do not do it: hipcc fuses two adjacent 8-byte reads into ds_read2_b64, which runs at the 4-byte rate.)
+            typedef T T4 __attribute__((ext_vector_type(4)));
+            const int o0 = (tY.idx[0] - cjy0) * RS + cb, o1 = (tY.idx[1] - cjy0) * RS + cb, o2 = (tY.idx[2] - cjy0) * RS + cb,
+                      o3 = (tY.idx[3] - cjy0) * RS + cb;
+            const T4 *q0 = reinterpret_cast<const T4 *>(__builtin_assume_aligned(rows + o0, 4 * sizeof(T))),
+                     *q1 = reinterpret_cast<const T4 *>(__builtin_assume_aligned(rows + o1, 4 * sizeof(T))),
+                     *q2 = reinterpret_cast<const T4 *>(__builtin_assume_aligned(rows + o2, 4 * sizeof(T))),
+                     *q3 = reinterpret_cast<const T4 *>(__builtin_assume_aligned(rows + o3, 4 * sizeof(T)));
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                acc[t] += tY.w[0] * q0[t] + tY.w[1] * q1[t] + tY.w[2] * q2[t] + tY.w[3] * q3[t];
+                if (t % 4 == 0) {
+                    const T4 v0 = q0[t / 4], v1 = q1[t / 4], v2 = q2[t / 4], v3 = q3[t / 4];
+                    acc[t] += tY.w[0] * v0.x + tY.w[1] * v1.x + tY.w[2] * v2.x + tY.w[3] * v3.x;
+                    acc[t + 1] += tY.w[0] * v0.y + tY.w[1] * v1.y + tY.w[2] * v2.y + tY.w[3] * v3.y;
+                    acc[t + 2] += tY.w[0] * v0.z + tY.w[1] * v1.z + tY.w[2] * v2.z + tY.w[3] * v3.z;
+                    acc[t + 3] += tY.w[0] * v0.w + tY.w[1] * v1.w + tY.w[2] * v2.w + tY.w[3] * v3.w;
+                }
                 // pin the accumulator updates in place, 8 outputs (32 reads in flight) at a time: left alone, instruction
                 // selection sinks all NT x 4 fmas below all NT x 4 LDS reads (256 VGPRs, 2 blocks per CU, AGPR spills)
                 if (t % 8 == 7)
