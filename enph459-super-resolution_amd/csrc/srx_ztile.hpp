@@ -26,6 +26,9 @@
 #ifndef SRX_ZTILE_NSY
 #define SRX_ZTILE_NSY 1
 #endif
+#ifndef SRX_ZTILE_LOAD_EDGES_FIRST
+#define SRX_ZTILE_LOAD_EDGES_FIRST 1
+#endif
 #ifndef SRX_ZTILE_HOLD
 #define SRX_ZTILE_HOLD 1  // the pre-update state stays in 64 more registers (216 in all: two tiles per CU) instead of being read again
                           // for the update: 245 -> 180 MB of HBM traffic per iteration of a 3072 x 4096 frame, 48.4 -> 43.9 us (eight
@@ -256,9 +259,12 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     // ================= stage A: column layout.  a[i] = region (row 64 s + i, column 64 u + lane) =================
     float a[64], r[64];
     const int vc0 = (pc0 + 64 * u + lane) * 4, sr0 = (pr0 + 64 * s) * WP * 4;
+    // the six rows the halo exchange of the first blur sends first: its LDS stores and barrier then run under the other 58 loads
 #pragma unroll
-    for (int i = 0; i < 64; i++)
+    for (int k = 0; k < 64; k++) {
+        const int i = SRX_ZTILE_LOAD_EDGES_FIRST ? (k < 3 ? k : (k < 6 ? 58 + k : k - 3)) : k;
         a[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+    }
 #if SRX_ZTILE_HOLD
     float hold[64];
 #pragma unroll
