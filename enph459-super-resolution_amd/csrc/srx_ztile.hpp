@@ -217,11 +217,11 @@ __global__ void __launch_bounds__(256)
 }
 
 // =========================================================================================================================
-// One iteration on one tile.  grid (tiles_x, tiles_y, B), block 1024 = 16 waves: wave (s, u) owns the 64 x 64 block at region rows
-// 64 s, columns 64 u (the layout of k_ibp_patch: four waves per SIMD hide each other's LDS and memory waits; the first version,
-// 8 waves x 128 values in 256 registers, ran at two waves per SIMD and was slower than the two-kernel path it replaces).
+// One iteration on one tile.  grid (tiles_x, tiles_y, B), block 256 NSY: wave (s, u) owns the 64 x 64 block at region rows 64 s,
+// columns 64 u (the block layouts of k_ibp_patch; NSY = 1: four waves side by side).
 // State and operand planes are zero-padded (image at (6, 6)), so no load is predicated; a store of a pixel this tile does not
-// own (or outside the image) goes to the plane's trash row / out of the buffer's range.
+// own (or outside the image) goes to the plane's trash row / out of the buffer's range.  epart: this iteration's per-tile MSE
+// partial sums (or null); eprev: the previous iteration's, which one interior tile adds up into err_prev[item * err_stride].
 // =========================================================================================================================
 __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart,
