@@ -56,7 +56,8 @@ typedef enum {
 #define SRX_FLAG_COMPOSED 1u /* force the literal per-frame composition of the primitives */
 #define SRX_FLAG_FUSED 2u    /* require a fused path; SRX_E_UNSUPPORTED if not eligible */
 #define SRX_FLAG_PER_FRAME 4u /* fused, but never the "mosaic" (common-fraction, depth-to-space) formulation */
-#define SRX_FLAG_TILES 8u     /* mosaic formulation, but never the patch-resident kernel (one workgroup per 256x256 HR patch) */
+#define SRX_FLAG_TILES 8u     /* mosaic formulation on the tile kernels only: neither the patch-resident kernel (one workgroup per
+                               * 256x256 HR patch) nor the one-launch-per-iteration kernel for integer HR shifts */
 /* Diagnostic path switches: each selects between implementations that the tests hold to the same results.  They are call
  * arguments (no environment variable alters what a call computes). */
 #define SRX_FLAG_DIAG_NO_ZERO_FUSE 0x100u      /* delta = 0: separate blur and index-map kernels */
@@ -67,8 +68,9 @@ typedef enum {
 int srx_version(void);
 const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
- * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch), "mosaic" (all shifts
- * share one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "fused"
+ * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch), "ztile" (mosaic
+ * formulation at integer HR shifts on frames of at least 128x128: one launch per iteration on register-resident tiles),
+ * "mosaic" (all shifts share one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "fused"
  * (per-frame tile kernels), "composed" (primitives, frame by frame). */
 const char *srx_last_path(void);
 
