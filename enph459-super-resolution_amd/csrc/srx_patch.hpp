@@ -29,6 +29,9 @@
 namespace srx {
 namespace patch {
 
+#ifndef SRX_PARK16
+#define SRX_PARK16 1
+#endif
 #ifndef SRX_ADDTID
 #define SRX_ADDTID 1
 #endif
@@ -223,6 +226,21 @@ __global__ void __launch_bounds__(256)
     near_coords(t, exy, exx, nby, nbx, ngy, ngx, dst);
     const int Wg = PN + 27, ni = mosaic::near_index(ngy + 13, ngx + 13, Wg, PBy, PBx);
     Mn[(size_t)b * NN_PAD + t] = make_float2(Mg[((size_t)b * Wg + ngy + 13) * Wg + ngx + 13], Mu[(size_t)b * NB + ni]);
+}
+
+// 16 bytes per lane through a buffer descriptor: the parked state travels as four rows per instruction (a CU issues a vector
+// memory instruction every ~9 cycles whatever its width -- 12 descriptor loads took a wave 1.7 K cycles to issue -- so the 64 + 64
+// one-word stores and loads that parked and re-read the state were a quarter of the iteration's critical path)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float x, float y, float z, float w)
+{
+    u32x4 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+}
+__device__ __forceinline__ void ld4(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float &x, float &y, float &z, float &w)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z), w = __uint_as_float(v.w);
 }
 
 // two consecutive words through a buffer descriptor (32-bit lane offset; out of range reads 0)
@@ -568,6 +586,13 @@ __global__ void __launch_bounds__(1024)
         for (int i = 0; i < 64; i++)
             a[i] = fused::buf_load<float>(rs_in, l4 + (i & 3) * PN * 4, cb0 + (i >> 2) * PN * 16);
     }
+#if SRX_PARK16
+    // The parked state has its own layout inside hr_out (wave, row quad, lane: 16 bytes per lane and instruction).  When the call is
+    // in place (hr_in == hr_out) no wave may park before every wave has its initial state in registers.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int park0 = wave * 16384;  // byte offset of this wave's 64 x 64 block in the parking layout
+#endif
     for (int it = 0; it < n_iter; it++) {
         float r[64];
         // Everything derived from the lane index (LDS and global addresses, predicates) and from the block offsets is re-derived
@@ -588,9 +613,17 @@ __global__ void __launch_bounds__(1024)
         SRX_PSTAMP(0);
         // ================= stage A: column layout, lane = column 64 u + lane, a[i] = row 64 s + i =================
         if (!(SRX_PATCH_DBG & 8)) {
+#if SRX_PARK16
+            int pk = park0;
+            asm volatile("" : "+s"(pk));
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                st4(rs_out, l4 * 4, pk + q * 1024, a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+#else
 #pragma unroll
             for (int i = 0; i < 64; i++)
                 fused::buf_store<float>(a[i], rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
+#endif
         }
         blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
         __builtin_amdgcn_sched_barrier(0);
@@ -826,9 +859,21 @@ __global__ void __launch_bounds__(1024)
                       [&](int q) {
                           // the parked state in 16-row batches, two in flight: batch q is consumed by quarter q of the blur
                           auto load16 = [&](float(&ld)[16], int bq) {
+#if SRX_PARK16
+                              int pk = park0;
+                              asm volatile("" : "+s"(pk));
+#pragma unroll
+                              for (int q = 0; q < 4; q++) {
+                                  if (SRX_PATCH_DBG & 2)
+                                      ld[4 * q] = ld[4 * q + 1] = ld[4 * q + 2] = ld[4 * q + 3] = 1.f;
+                                  else
+                                      ld4(rs_out, l4 * 4, pk + (4 * bq + q) * 1024, ld[4 * q], ld[4 * q + 1], ld[4 * q + 2], ld[4 * q + 3]);
+                              }
+#else
 #pragma unroll
                               for (int i = 0; i < 16; i++)
                                   ld[i] = (SRX_PATCH_DBG & 2) ? 1.f : fused::buf_load<float>(rs_out, l4 + (i & 3) * PN * 4, cbl + (4 * bq + (i >> 2)) * PN * 16);
+#endif
                           };
                           if (q == 0) {
                               SRX_PSTAMP(13);
@@ -850,6 +895,11 @@ __global__ void __launch_bounds__(1024)
 #undef SRX_STAGE_LOCALS
     }
     {
+#if SRX_PARK16
+        // the result goes out in image layout, over the parking layout: not before every wave has re-read its last parked rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#endif
         const int l4 = (tid0 & 63) * 4;
 #pragma unroll
         for (int i = 0; i < 64; i++)
