@@ -105,10 +105,10 @@ struct PatchArgs {
 
 // per-call device tables of the patch path
 struct PatchTabs {
-    const float *Mt;            // [B][256 gx][256 gy] far-field LR mosaic, transposed
-    const unsigned *Mt8;        // [B][64][256 gy]: the same as bytes, 4 columns per word (valid where m8[b] != 0)
+    const float *Mt;            // [B][64 column quads][256 gy][4] far-field LR mosaic, transposed, four columns interleaved
+    const unsigned *Mt8;        // [B][16][256 gy][4]: the same as bytes, 4 columns per word, four words interleaved (valid where m8[b] != 0)
     const int *m8;              // [B]: every far-field M of the patch is an integer in [0, 255]
-    const float *Ct;            // [256 gx][256 gy] count map, transposed (unused when c01)
+    const float *Ct;            // [64 column quads][256 gy][4] count map, as Mt (unused when c01)
     const AxisW *aw;            // [2]: y, x
     const uint2 *nrec;          // [NN_PAD]  x = cnt | cu << 8 | dst << 16, y = strip offset of the pixel's own Y sample
     const uint2 *nent;          // [ngrp][NN_PAD] four 16-bit strip offsets per group
@@ -139,8 +139,8 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
 }
 
 // ---- once per call: transposed far-field operands ---------------------------------------------------------------------
-// Mt[b][gx][gy] = M[b][gy + 13][gx + 13] (and Ct from C, plane index B): in row layout a lane is a row, so a wave's load of
-// one column register reads 64 consecutive gy.  grid (8, 8, B + 1), block (32, 8).
+// Mt[b][gx / 4][gy][gx % 4] = M[b][gy + 13][gx + 13] (and Ct from C, plane index B): in row layout a lane is a row, and one 16-byte
+// load brings four of its columns (64 consecutive gy x 16 bytes per wave-instruction).  grid (8, 8, B + 1), block (32, 8).
 // Also Mt8: the same values as bytes, four columns per word, and m8[b] (preset non-zero by the host) cleared when a value of
 // patch b is not an integer in [0, 255] (uint8 sensor frames with at most one sample per HR pixel: one quarter of the bytes).
 __global__ void __launch_bounds__(256)
@@ -160,16 +160,22 @@ __global__ void __launch_bounds__(256)
         t[r][threadIdx.x] = v;
     }
     __syncthreads();
-    for (int r = threadIdx.y; r < 32; r += 8)
-        dst[(size_t)(x0 + r) * PN + y0 + threadIdx.x] = t[threadIdx.x][r];
+    // transposed, FOUR COLUMNS INTERLEAVED: [column quad][row][4] -- a lane of k_ibp_patch (row layout: lane = row) reads four of
+    // its columns with one 16-byte load
+    const int g = threadIdx.y;  // 8 groups of 4 columns
+    reinterpret_cast<float4 *>(dst)[(size_t)(x0 / 4 + g) * PN + y0 + threadIdx.x] =
+        make_float4(t[threadIdx.x][4 * g], t[threadIdx.x][4 * g + 1], t[threadIdx.x][4 * g + 2], t[threadIdx.x][4 * g + 3]);
     if (b < B) {
-        const int g = threadIdx.y;  // 8 groups of 4 columns
         const unsigned w = (unsigned)t[threadIdx.x][4 * g] | (unsigned)t[threadIdx.x][4 * g + 1] << 8 |
                            (unsigned)t[threadIdx.x][4 * g + 2] << 16 | (unsigned)t[threadIdx.x][4 * g + 3] << 24;
-        Mt8[(size_t)b * (PN / 4) * PN + (size_t)(x0 / 4 + g) * PN + y0 + threadIdx.x] = w;
-        if (!ok)
-            atomicAnd(&m8[b], 0);
+        const int wr = x0 / 4 + g;  // word row = column quad; four word rows interleaved the same way: [wr / 4][row][4]
+        Mt8[(size_t)b * (PN / 4) * PN + ((size_t)(wr >> 2) * PN + y0 + threadIdx.x) * 4 + (wr & 3)] = w;
     }
+    // one atomic per block, not one per pixel: a batch of float-valued patches used to spend 25 ms here (65 536 atomics per patch on
+    // one address) -- twice the time of the 80 iterations that followed
+    const bool bad = __syncthreads_or(b < B && !ok);
+    if (bad && threadIdx.x == 0 && threadIdx.y == 0)
+        atomicAnd(&m8[b], 0);
 }
 
 // near-band pixel t of the patch enumeration -> natural coordinates and offset in the G strips
@@ -572,7 +578,7 @@ __global__ void __launch_bounds__(1024)
     const int nn = pa.nn;
     const float sn = pa.sn;
     const int cb0 = (64 * s * PN + 64 * u) * 4;  // byte offset of this wave's block in column layout (row pitch PN)
-    const int tb0 = (64 * u * PN + 64 * s) * 4;  // ... in the transposed planes (Mt, Ct): register = column, lane = row
+    const int tb0 = (16 * u * PN + 64 * s) * 16;  // ... in the transposed planes (Mt, Ct: [column quad][row][4]): lane = row
     // 0/1 count map of a full phase grid: this wave's 64 row bits (row layout: bit = lane) and 64 column bits
     const unsigned long long rmask = C01 ? pa.ry[s] : 0ull, cmask = C01 ? pa.rx[u] : 0ull;
 
@@ -603,7 +609,7 @@ __global__ void __launch_bounds__(1024)
     int tid = tid0;                                        \
     asm volatile("" : "+v"(tid));                          \
     const int lane = tid & 63, l4 = lane * 4;              \
-    int cbl = cb0, tbl = tb0, m8l = (16 * u * PN + 64 * s) * 4; \
+    int cbl = cb0, tbl = tb0, m8l = (4 * u * PN + 64 * s) * 16; \
     asm volatile("" : "+s"(cbl), "+s"(tbl), "+s"(m8l));    \
     (void)tbl, (void)m8l, (void)cbl, (void)l4
         float yex = 0.f;
@@ -700,8 +706,11 @@ __global__ void __launch_bounds__(1024)
         unsigned m8w[16];
         if (m8) {
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                m8w[k] = (SRX_PATCH_DBG & 1) ? 0x01020304u : __builtin_amdgcn_raw_buffer_load_b32(rsM8, l4 + (k & 3) * PN * 4, m8l + (k >> 2) * PN * 16, 0);
+            for (int q = 0; q < 4; q++) {
+                const u32x4 v = (SRX_PATCH_DBG & 1) ? u32x4{0x01020304u, 0x01020304u, 0x01020304u, 0x01020304u}
+                                                    : __builtin_amdgcn_raw_buffer_load_b128(rsM8, l4 * 4, m8l + q * PN * 16, 0);
+                m8w[4 * q] = v.x, m8w[4 * q + 1] = v.y, m8w[4 * q + 2] = v.z, m8w[4 * q + 3] = v.w;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(7);
@@ -743,6 +752,7 @@ __global__ void __launch_bounds__(1024)
             asm volatile("" : "+s"(cm));
             float gn[3] = {0.f, 0.f, 0.f};  // squares of the first three columns: near band when u == 0 (subtracted again below)
             if (m8) {
+                float cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 64; j++) {
                     const float mv = (float)((m8w[j >> 2] >> (8 * (j & 3))) & 255u);
@@ -752,7 +762,9 @@ __global__ void __launch_bounds__(1024)
                         g = on ? fmaf(-crow, r[j], mv) : 0.f;
                         w = 1.f;
                     } else {
-                        const float cv = fused::buf_load<float>(rsC, l4 + (j & 3) * PN * 4, tbl + (j >> 2) * PN * 16);
+                        if ((j & 3) == 0)
+                            ld4(rsC, l4 * 4, tbl + (j >> 2) * PN * 16, cq[0], cq[1], cq[2], cq[3]);
+                        const float cv = cq[j & 3];
                         g = fmaf(-cv, r[j], mv);
                         w = mosaic::rcp_count(cv);
                     }
@@ -767,10 +779,15 @@ __global__ void __launch_bounds__(1024)
                 for (int j0 = 0; j0 < 64; j0 += 16) {
                     float mv[16], cv[16];
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        mv[j] = fused::buf_load<float>(rsM, l4 + (j & 3) * PN * 4, tbl + ((j0 + j) >> 2) * PN * 16);
-                        cv[j] = C01 ? (((cm >> (j0 + j)) & 1ull) ? crow : 0.f)
-                                    : fused::buf_load<float>(rsC, l4 + (j & 3) * PN * 4, tbl + ((j0 + j) >> 2) * PN * 16);
+                    for (int q = 0; q < 4; q++) {
+                        ld4(rsM, l4 * 4, tbl + ((j0 >> 2) + q) * PN * 16, mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
+                        if (C01) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++)
+                                cv[4 * q + c] = ((cm >> (j0 + 4 * q + c)) & 1ull) ? crow : 0.f;
+                        } else {
+                            ld4(rsC, l4 * 4, tbl + ((j0 >> 2) + q) * PN * 16, cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 16; j++) {

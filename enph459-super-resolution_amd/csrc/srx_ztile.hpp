@@ -134,13 +134,14 @@ __global__ void __launch_bounds__(256)
     k_ztile_pack(const float *__restrict__ Mt, const float *__restrict__ Ct, int HP, int WP, unsigned *__restrict__ CM, int *__restrict__ cmok)
 {
     const int py = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
-    if (py >= HP)
-        return;
-    const size_t o0 = (size_t)(2 * k) * HP + py, o1 = o0 + HP;
-    const float m0 = Mt[(size_t)b * HP * WP + o0], m1 = Mt[(size_t)b * HP * WP + o1], c0 = Ct[o0], c1 = Ct[o1];
-    const bool ok = m0 == rintf(m0) && m1 == rintf(m1) && m0 >= 0.f && m1 >= 0.f && m0 < 4096.f && m1 < 4096.f && c0 < 16.f && c1 < 16.f;
-    CM[((size_t)b * (WP / 2) + k) * HP + py] = ((unsigned)c0 << 12 | (unsigned)m0) | ((unsigned)c1 << 12 | (unsigned)m1) << 16;
-    if (!ok)
+    bool ok = true;
+    if (py < HP) {
+        const size_t o0 = (size_t)(2 * k) * HP + py, o1 = o0 + HP;
+        const float m0 = Mt[(size_t)b * HP * WP + o0], m1 = Mt[(size_t)b * HP * WP + o1], c0 = Ct[o0], c1 = Ct[o1];
+        ok = m0 == rintf(m0) && m1 == rintf(m1) && m0 >= 0.f && m1 >= 0.f && m0 < 4096.f && m1 < 4096.f && c0 < 16.f && c1 < 16.f;
+        CM[((size_t)b * (WP / 2) + k) * HP + py] = ((unsigned)c0 << 12 | (unsigned)m0) | ((unsigned)c1 << 12 | (unsigned)m1) << 16;
+    }
+    if (__syncthreads_or(!ok) && threadIdx.x == 0)  // one atomic per block: float-valued frames would otherwise queue millions on one word
         atomicAnd(&cmok[b], 0);
 }
 

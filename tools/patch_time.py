@@ -8,7 +8,9 @@ from sr_mi355x import api as S, synth, _lib
 f, shifts = 4, synth.phase_shifts(4)
 Bt = int(os.environ.get("PT_B", "1024"))
 g = torch.Generator(device="cuda").manual_seed(1)
-lr = torch.round(torch.rand((Bt, 16, 64, 64), device="cuda", generator=g) * 255)
+lr = torch.rand((Bt, 16, 64, 64), device="cuda", generator=g) * 255
+if not os.environ.get("PT_FLOAT"):  # PT_FLOAT=1: non-integer samples (the float form of the mosaic)
+    lr = torch.round(lr)
 hr0 = torch.rand((Bt, 256, 256), device="cuda", generator=g) * 255
 best = 1e9
 for rep in range(4):

@@ -15,7 +15,9 @@ import sr_mi355x as S  # noqa: E402
 from sr_mi355x import _lib, synth  # noqa: E402
 
 f, shifts, psf, B = 4, synth.phase_shifts(4), synth.gaussian_psf(), int(os.environ.get("STAMPS_B", "1024"))
-lr = torch.round(torch.rand((B, 16, 64, 64), device="cuda") * 255)
+lr = torch.rand((B, 16, 64, 64), device="cuda") * 255
+if not os.environ.get("PT_FLOAT"):  # PT_FLOAT=1: non-integer samples (the float form of the mosaic)
+    lr = torch.round(lr)
 saa = S.shift_and_add_batched(lr, shifts, f)
 S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
 NPH = 15
