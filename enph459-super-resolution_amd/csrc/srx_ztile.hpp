@@ -20,7 +20,10 @@
 // Near band (LR row / column 0 replicated into SciPy's pad: pixels g < -n_min, in the first rows / columns of the IMAGE): tiles
 // on the top / left image edge evaluate the per-pixel lists of k_build_near from two LDS strips of b, as k_ibp_patch does.
 // The state ping-pongs between two zero-padded planes (a tile reads its neighbours' pixels of the previous iteration); M and C
-// travel as one packed 16-bit operand per pixel when the samples are 8-bit integers (k_ztile_pack).
+// travel as one packed 16-bit operand per pixel when the samples are 8-bit integers (k_ztile_pack).  Both kinds of plane are
+// interleaved for 8-byte accesses (state: row pairs, operands: word pairs): a CU issues one vector memory instruction per ~9
+// cycles whatever its width, and a tile's 64 + 64 + 32 one-word loads and stores were a quarter of its 36 K cycles
+// (41.4 -> 39.5 us per iteration on a 3072 x 4096 frame).
 #pragma once
 #include "srx_patch.hpp"
 #ifndef SRX_ZTILE_NSY
@@ -44,12 +47,15 @@ namespace ztile {
 using patch::f8;
 using patch::sload8;
 using patch::TSD;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 
 constexpr int RG = 256;           // region width (and the stride of the strips)
 constexpr int HALO = 6;           // 3 (blur) + 3 (adjoint blur)
 constexpr int VT = RG - 2 * HALO; // 244 valid columns per tile
 constexpr int NSY = SRX_ZTILE_NSY;  // block rows per tile: region height 64 NSY (1: see the header for what 2 and 4 measured)
 constexpr int RGY = 64 * NSY, VTY = RGY - 2 * HALO;
+static_assert(HALO % 2 == 0 && VTY % 2 == 0, "row pairs: ownership boundaries and tile origins must be even");
 constexpr int SW = 4;             // strip pitch (rows of the top strip / columns of the left strip)
 // LDS: 16 wave regions of srx_patch.hpp (transpose image + exchange slots), then the near-band strips
 // The strips are four rows of RG words (top band) / RGY rows of four words (left band).  They live in the parts of the wave regions
@@ -63,7 +69,8 @@ static_assert(LDS_WORDS * 4 <= (NSY == 1 ? 40 : NSY == 2 ? 80 : 160) * 1024, "LD
 
 struct ZArgs {
     int H, W, tiles_x, tiles_y;
-    int HP, WP;              // padded state / operand planes: image at (6, 6), zero border, HP + 1 rows (the last is a trash row)
+    int HP, WP;              // padded state / operand planes: image at (6, 6), zero border; the state planes hold ROW PAIRS
+                             // interleaved ([HP / 2 + 1][WP][2]: 8 bytes per lane and memory instruction) and end in a trash pair
     int exy, exx, nby, nbx;  // n_max (samples above the image), -n_min (near-band rows inside it), per axis
     int Ey, Ex;              // padded Y index = rho + E (11)
     int WT, LN, TOPN;        // near-band enumeration: top band [exy + nby][WT], then left band [H - nby][LN]
@@ -139,24 +146,30 @@ __global__ void __launch_bounds__(256)
         const size_t o0 = (size_t)(2 * k) * HP + py, o1 = o0 + HP;
         const float m0 = Mt[(size_t)b * HP * WP + o0], m1 = Mt[(size_t)b * HP * WP + o1], c0 = Ct[o0], c1 = Ct[o1];
         ok = m0 == rintf(m0) && m1 == rintf(m1) && m0 >= 0.f && m1 >= 0.f && m0 < 4096.f && m1 < 4096.f && c0 < 16.f && c1 < 16.f;
-        CM[((size_t)b * (WP / 2) + k) * HP + py] = ((unsigned)c0 << 12 | (unsigned)m0) | ((unsigned)c1 << 12 | (unsigned)m1) << 16;
+        // two words (four columns) interleaved: [WP / 4][HP][2]
+        CM[(((size_t)b * (WP / 4) + (k >> 1)) * HP + py) * 2 + (k & 1)] = ((unsigned)c0 << 12 | (unsigned)m0) | ((unsigned)c1 << 12 | (unsigned)m1) << 16;
     }
     if (__syncthreads_or(!ok) && threadIdx.x == 0)  // one atomic per block: float-valued frames would otherwise queue millions on one word
         atomicAnd(&cmok[b], 0);
 }
 
-// state planes: [B][HP + 1][WP], image at (6, 6).  copy-in (the border was zeroed by a memset) and copy-out.  grid (ceil(W/256), H, B)
+// state planes: [B][HP / 2 + 1][WP][2] (row pairs interleaved), image at (6, 6).  copy-in (the border was zeroed by a memset) and
+// copy-out.  grid (ceil(W/256), H, B)
+__device__ __forceinline__ size_t state_off(int b, int row, int col, int HP, int WP)
+{
+    return (size_t)b * (HP + 2) * WP + ((size_t)(row >> 1) * WP + col) * 2 + (row & 1);
+}
 __global__ void __launch_bounds__(256) k_ztile_copy_in(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x < W)
-        dst[((size_t)b * (HP + 1) + y + HALO) * WP + x + HALO] = src[((size_t)b * H + y) * W + x];
+        dst[state_off(b, y + HALO, x + HALO, HP, WP)] = src[((size_t)b * H + y) * W + x];
 }
 __global__ void __launch_bounds__(256) k_ztile_copy_out(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x < W)
-        dst[((size_t)b * H + y) * W + x] = src[((size_t)b * (HP + 1) + y + HALO) * WP + x + HALO];
+        dst[((size_t)b * H + y) * W + x] = src[state_off(b, y + HALO, x + HALO, HP, WP)];
 }
 
 // near-band pixel T of the image enumeration -> natural coordinates
@@ -242,7 +255,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     auto Gt = [&](int row, int col) -> float & { return lds[row * patch::RW + GT_OFF + col]; };
     double *part = reinterpret_cast<double *>(lds + OFF_PART);
     const float *awy = tb.aw[0].kb, *awx = tb.aw[1].kb;
-    const size_t splane = (size_t)(HP + 1) * WP, oplane = (size_t)HP * WP;
+    const size_t splane = (size_t)(HP + 2) * WP, oplane = (size_t)HP * WP;
     const __amdgpu_buffer_rsrc_t rs_src = fused::plane_rsrc(hr_src + (size_t)b * splane, splane);
     const __amdgpu_buffer_rsrc_t rs_dst = fused::plane_rsrc(hr_dst + (size_t)b * splane, splane);
     const bool top = ty == 0, left = tx == 0;  // block-uniform: tiles holding the near band
@@ -259,12 +272,17 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     SRX_PSTAMP(0);
     // ================= stage A: column layout.  a[i] = region (row 64 s + i, column 64 u + lane) =================
     float a[64], r[64];
-    const int vc0 = (pc0 + 64 * u + lane) * 4, sr0 = (pr0 + 64 * s) * WP * 4;
+    // row pairs: lane = column, one 8-byte access = rows 2k, 2k + 1 of the region (pr0 is even: pairs of the plane are pairs of the region)
+    const int vc0 = (pc0 + 64 * u + lane) * 8, sr0 = ((pr0 + 64 * s) >> 1) * WP * 8;
+    auto ld2 = [&](int k, float &x, float &y) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_src, vc0, sr0 + k * WP * 8, 0);
+        x = __uint_as_float(v.x), y = __uint_as_float(v.y);
+    };
     // the six rows the halo exchange of the first blur sends first: its LDS stores and barrier then run under the other 58 loads
 #pragma unroll
-    for (int k = 0; k < 64; k++) {
-        const int i = SRX_ZTILE_LOAD_EDGES_FIRST ? (k < 3 ? k : (k < 6 ? 58 + k : k - 3)) : k;
-        a[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+    for (int k = 0; k < 32; k++) {
+        const int i = SRX_ZTILE_LOAD_EDGES_FIRST ? (k < 2 ? k : (k < 4 ? 28 + k : k - 2)) : k;  // pairs 0, 1, 30, 31 first
+        ld2(i, a[2 * i], a[2 * i + 1]);
     }
 #if SRX_ZTILE_HOLD
     float hold[64];
@@ -289,14 +307,19 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     // the operands of the G step, 16 bits per pixel (16 columns = 8 words per batch, one batch ahead of its use: the first is
     // in flight during the row blur)
     const int cmok = __builtin_amdgcn_readfirstlane(tb.cmok[b]);
-    const size_t cplane = (size_t)(WP / 2) * HP;
+    const size_t cplane = (size_t)(WP / 2) * HP;  // words: [WP / 4][HP][2]
     const __amdgpu_buffer_rsrc_t rsP = fused::plane_rsrc(tb.CM + (size_t)b * cplane, cplane);
-    const int sp0 = ((pc0 + 64 * u) / 2) * HP * 4, vp = (pr0 + rr) * 4;
+    const int sp0 = ((pc0 + 64 * u) / 4) * HP * 8, vp = (pr0 + rr) * 4, vp2 = (pr0 + rr) * 8;  // (pc0 + 64 u) / 2 is even
+    auto ldcm = [&](unsigned(&w)[8], int k0) {  // words k0 .. k0 + 7 of this lane's row: four 8-byte loads
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsP, vp2, sp0 + (k0 / 2 + k) * HP * 8, 0);
+            w[2 * k] = v.x, w[2 * k + 1] = v.y;
+        }
+    };
     unsigned cma[8], cmb[8];
     if (cmok) {
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            cma[k] = __builtin_amdgcn_raw_buffer_load_b32(rsP, vp, sp0 + k * HP * 4, 0);
+        ldcm(cma, 0);
     }
     patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, sload8(awx));
     SRX_PSTAMP(5);
@@ -396,9 +419,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
                 unsigned(&cur)[8] = (j0 & 16) ? cmb : cma;
                 unsigned(&nxt)[8] = (j0 & 16) ? cma : cmb;
                 if ((j0 & 8) == 0 && j0 + 16 < 64) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        nxt[k] = __builtin_amdgcn_raw_buffer_load_b32(rsP, vp, sp0 + ((j0 + 16) / 2 + k) * HP * 4, 0);
+                    ldcm(nxt, (j0 + 16) / 2);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -454,7 +475,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     SRX_PSTAMP(10);
     // ---- update and store.  Rows this tile does not own (or below the image) go to the trash row; columns it does not own
     // (or right of the image) get an offset beyond the buffer's range, which drops the store.
-    const int trash = HP * WP * 4;
+    const int trash = (HP >> 1) * WP * 8;  // the trash pair
     const int cc = 64 * u + lane;
     const int vst = (cc >= HALO && cc < RG - HALO && pc0 + cc - HALO < W) ? vc0 : 0x7ffffff0;
     // loads and arithmetic first, every store at the very end: vmcnt counts loads and stores in one order, so a wait for a batch of
@@ -467,16 +488,16 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     {
         float hv[16], hw[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            hv[i] = fused::buf_load<float>(rs_src, vc0, sr0 + i * WP * 4);
+        for (int k = 0; k < 8; k++)
+            ld2(k, hv[2 * k], hv[2 * k + 1]);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float(&cur)[16] = (q & 1) ? hw : hv;
             float(&nxt)[16] = (q & 1) ? hv : hw;
             if (q < 3) {
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    nxt[i] = fused::buf_load<float>(rs_src, vc0, sr0 + (16 * (q + 1) + i) * WP * 4);
+                for (int k = 0; k < 8; k++)
+                    ld2(8 * (q + 1) + k, nxt[2 * k], nxt[2 * k + 1]);
             }
 #pragma unroll
             for (int i = 0; i < 16; i++)
@@ -487,10 +508,12 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
 #endif
     SRX_PSTAMP(11);
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const int rw = 64 * s + i;  // wave-uniform
+    for (int k = 0; k < 32; k++) {
+        const int rw = 64 * s + 2 * k;  // wave-uniform; HALO and RGY - HALO are even: a pair is owned as a whole or not at all
         const bool rok = rw >= HALO && rw < RGY - HALO && pr0 + rw - HALO < H;
-        fused::buf_store<float>(a[i], rs_dst, vst, rok ? sr0 + i * WP * 4 : trash);
+        const bool in1 = pr0 + rw + 1 - HALO < H;  // an odd image height: the pair's second row is the zero border, and stays zero
+        const u32x2 v = {__float_as_uint(a[2 * k]), __float_as_uint(in1 ? a[2 * k + 1] : 0.f)};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs_dst, vst, rok ? sr0 + k * WP * 8 : trash, 0);
     }
     SRX_PSTAMP(12);
 }
@@ -500,7 +523,7 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
 {
     const size_t ngrp = ((size_t)N + 3) / 4, NT = (size_t)6 * (W + 4) + (size_t)H * 6;
     const size_t ty = cdiv(H, VTY), tx = cdiv(W, VT), HP = ty * VTY + 2 * HALO, WP = tx * VT + 2 * HALO;
-    return align_up((size_t)B * HP * WP * 4) + 2 * align_up((size_t)B * (HP + 1) * WP * 4) + align_up(HP * WP * 4) +
+    return align_up((size_t)B * HP * WP * 4) + 2 * align_up((size_t)B * (HP + 2) * WP * 4) + align_up(HP * WP * 4) +
            align_up((size_t)B * (WP / 2) * HP * 4) + align_up((size_t)B * 4) +
            align_up(2 * sizeof(patch::AxisW)) + align_up(NT * 4) + align_up(ngrp * NT * 16) + align_up((size_t)B * NT * 8) +
            2 * align_up((size_t)B * ty * tx * 8);
@@ -528,7 +551,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
     za.ngrp = NS / 4;
     za.sn = (float)step / (float)N;
     const int NT = za.TOPN + (H - za.nby) * za.LN, ntiles = za.tiles_x * za.tiles_y;
-    const size_t splane = (size_t)(HP + 1) * WP;
+    const size_t splane = (size_t)(HP + 2) * WP;
     float *Mt = ar.take<float>((size_t)B * HP * WP), *s0 = ar.take<float>(B * splane), *s1 = ar.take<float>(B * splane),
           *Ct = ar.take<float>((size_t)HP * WP);
     unsigned *CM = ar.take<unsigned>((size_t)B * (WP / 2) * HP);
