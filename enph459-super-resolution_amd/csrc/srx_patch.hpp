@@ -252,7 +252,9 @@ __device__ __forceinline__ void ld4(__amdgpu_buffer_rsrc_t rs, int voff, int sof
 // two consecutive words through a buffer descriptor (32-bit lane offset; out of range reads 0)
 __device__ __forceinline__ uint2 ld_u2(__amdgpu_buffer_rsrc_t rs, int byte_off)
 {
-    return make_uint2(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0), __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off + 4, 0, 0));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+    return make_uint2(v.x, v.y);
 }
 
 // ---- wave-private 64 x 64 transpose through a 32-row LDS image ----------------------------------------------------------
