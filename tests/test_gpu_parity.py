@@ -227,6 +227,8 @@ FUSED_CFGS = {
     "f3_k5": (3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], "asym5", (60, 75), "fused"),
     "f2_nom5": (2, synth.NOMINAL_5, "gauss", (131, 200), "mosaic", "ztile"),  # integer HR shifts: pure depth-to-space; IBP on CU-resident tiles
     "f2_nom4_big": (2, synth.NOMINAL_4, "gauss", (150, 277), "mosaic", "ztile"),  # several 244-pixel tiles per axis, ragged last tiles
+    "f3_int_odd": (3, [(0.0, 0.0), (1.0 / 3, -2.0 / 3), (-2.0 / 3, 1.0 / 3), (1.0 / 3, 1.0 / 3)], "gauss", (45, 61), "mosaic", "ztile"),  # x3, odd HR height 135:
+    #                 the last row pair of the one-launch kernel's state planes is half image, half zero border
     "f4_nom4": (4, synth.NOMINAL_4, "asym", (70, 90), "mosaic"),
     "f4_ph16": (4, synth.phase_shifts(4), "gauss", (70, 90), "mosaic"),     # the bench workload: all fractions 0.5
     "f3_ph9": (3, synth.phase_shifts(3), "asym", (50, 66), "mosaic"),       # fractions 0 (3 phases centred on 0)
@@ -276,6 +278,28 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "fused"
     close(hr_p[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     np.testing.assert_allclose(errs_p[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
+
+
+def test_one_launch_kernel_float_frames():
+    """k_ibp_ztile on frames that are not 8-bit integers (rep means, calibrated frames): the float operand planes instead of the
+    packed 16-bit ones, against the oracle and the tile kernels."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, psf = 2, synth.NOMINAL_5, synth.gaussian_psf()
+    truth = synth.truth_image(300, 262, seed=5)
+    O.set_threads(8)
+    try:
+        lr = np.stack([O.forward_model(truth, psf, s, f) for s in shifts]) + 0.37  # fractional samples
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 7, 0.5)
+    finally:
+        O.set_threads(1)
+    hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 7, 0.5)
+    assert S.last_path() == "ztile"
+    close(hr[0].cpu().numpy(), hr_o, IBP_TOL["f32"])
+    np.testing.assert_allclose(errs[0].cpu().numpy(), err_o, rtol=ERR_RTOL["f32"])
+    hr_t, _ = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 7, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "mosaic" and float((hr - hr_t).abs().max()) < 5e-4
 
 
 def test_tiny_and_odd_inputs(prec):

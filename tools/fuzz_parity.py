@@ -58,6 +58,8 @@ def run(n_cases=100, seed=2026):
     for ci in range(n_cases):
         f, shifts, h, w, psf, n_iter, kind = random_case(rng)
         lr = np.clip(np.rint(rng.uniform(0, 255, (len(shifts), h, w))), 0, 255)
+        if rng.uniform() < 0.25:  # a quarter of the cases with fractional samples: the float forms of the mosaic / operand planes
+            lr = lr * 0.75 + 0.3
         saa_o = O.shift_and_add(list(lr), shifts, f)
         hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, n_iter, 0.5)
         for prec, tol in (("f64", 1e-8), ("f32", 1e-3)):
