@@ -44,3 +44,8 @@ def g_rag():
 @pytest.fixture(scope="session")
 def g_real():
     return load_golden("real_crops.npz")
+
+
+@pytest.fixture(scope="session")
+def g_frame():
+    return load_golden("frame_zero.npz")

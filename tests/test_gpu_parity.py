@@ -121,11 +121,47 @@ def test_ibp_c2_small(prec, g_c2s, n):
     np.testing.assert_allclose(errs, g_c2s["ibp4_errors"][:n], rtol=ERR_RTOL[prec])
 
 
+def u8_close(hr, ref):
+    """uint8 outputs (the reference's truncating quantiser, run_sr.py:303): <= 1 LSB, >= 99.9 % identical"""
+    q, qr = S.quantize_u8(hr).astype(np.int16), np.clip(ref, 0, 255).astype(np.uint8).astype(np.int16)
+    assert np.abs(q - qr).max() <= 1 and (q == qr).mean() >= 0.999, (np.abs(q - qr).max(), (q == qr).mean())
+
+
+@pytest.mark.parametrize("case", ["synth_gauss", "synth_measured_psf", "real_crop"])
+def test_ibp_frame_80_iterations_golden(prec, g_frame, case):
+    """The kernel behind the reference's shipped defaults (delta = 0 on frames: k_ibp_ztile in f32) against REFERENCE-generated
+    goldens at its full 80 iterations (mono_cal_target/run_sr.py:190-209): 144 x 280 HR = 3 x 2 ragged tiles."""
+    g = g_frame
+    if case == "real_crop":
+        lr, sh, psf, saa_ref, ref, eref = g["real_lr"], g["real_shifts"], g["psf_g"], g["real_saa"], g["real_ibp80"], g["real_errors"]
+    else:
+        lr, sh, saa_ref = g["lr5"], g["shifts5"], g["saa5"]
+        psf, ref, eref = (g["psf_g"], g["ibp5_80"], g["ibp5_errors"]) if case == "synth_gauss" else (g["psf_m"], g["ibp5m_80"], g["ibp5m_errors"])
+    lr = list(lr.astype(np.float64))
+    saa = S.shift_and_add(lr, sh, 2)
+    close(saa, saa_ref, PRIM_TOL[prec])
+    hr, errs = S.ibp(lr, sh, psf, saa_ref, 2, 80, 0.5, verbose=False)
+    if prec == "f32":
+        assert S.last_path() == "ztile"
+    close(hr, ref, IBP_TOL[prec])
+    np.testing.assert_allclose(errs, eref, rtol=ERR_RTOL[prec])
+    u8_close(hr, ref)
+    if case == "synth_gauss":
+        for n in (1, 10):
+            hr_n, errs_n = S.ibp(lr, sh, psf, saa_ref, 2, n, 0.5, verbose=False)
+            close(hr_n, g[f"ibp5_{n}"], IBP_TOL["f32"])  # stored as float32
+            np.testing.assert_allclose(errs_n, eref[:n], rtol=ERR_RTOL[prec])
+        truth = g["truth"].astype(np.float64)
+        assert synth.psnr(hr, ref) > 90.0 and abs(synth.psnr(hr, truth) - synth.psnr(ref, truth)) < 0.01
+
+
 def test_ibp_c2_full_psnr(prec, g_c2f):
     """Config C2 patch (f=4, N=16, 64x64 LR -> 256x256, 80 iterations): the north-star PSNR bar."""
     saa = S.shift_and_add(list(g_c2f["lr16"]), g_c2f["shifts16"], 4)
     close(saa, g_c2f["saa16"], PRIM_TOL[prec])
     hr, errs = S.ibp(list(g_c2f["lr16"]), g_c2f["shifts16"], g_c2f["psf_g"], saa, 4, 80, 0.5, verbose=False)
+    if prec == "f32":
+        assert S.last_path() == "patch"  # an eligibility regression would otherwise test the tile kernels silently
     ref, truth = g_c2f["ibp16_80"], g_c2f["truth"].astype(np.float64)
     close(hr, ref, IBP_TOL[prec])
     assert synth.psnr(hr, ref) > 90.0

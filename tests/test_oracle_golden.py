@@ -112,6 +112,28 @@ def test_ibp_c2_full(g_c2f):
     close(errs, g_c2f["ibp16_errors"])
 
 
+def test_ibp_frame_80_iterations(g_frame):
+    """delta = 0 frames of 144 x 280 HR pixels (large enough for the one-launch frame kernel), 80 iterations of the reference's ibp
+    (mono_cal_target/run_sr.py:190-209): synthetic N = 5 nominal with the Gaussian and the measured PSF, and a crop of the
+    committed mono_cal_target frames."""
+    g = g_frame
+    lr = list(g["lr5"].astype(np.float64))
+    close(O.shift_and_add(lr, g["shifts5"], 2), g["saa5"])
+    hr, errs = O.ibp(lr, g["shifts5"], g["psf_g"], g["saa5"], 2, 80, 0.5)
+    close(hr, g["ibp5_80"])
+    np.testing.assert_allclose(errs, g["ibp5_errors"], rtol=1e-10)
+    hr10, _ = O.ibp(lr, g["shifts5"], g["psf_g"], g["saa5"], 2, 10, 0.5)
+    close(hr10, g["ibp5_10"], 1e-4)  # stored as float32
+    hr, errs = O.ibp(lr, g["shifts5"], g["psf_m"], g["saa5"], 2, 80, 0.5)
+    close(hr, g["ibp5m_80"])
+    np.testing.assert_allclose(errs, g["ibp5m_errors"], rtol=1e-10)
+    lr = list(g["real_lr"].astype(np.float64))
+    close(O.shift_and_add(lr, g["real_shifts"], 2), g["real_saa"])
+    hr, errs = O.ibp(lr, g["real_shifts"], g["psf_g"], g["real_saa"], 2, 80, 0.5)
+    close(hr, g["real_ibp80"])
+    np.testing.assert_allclose(errs, g["real_errors"], rtol=1e-10)
+
+
 def test_ibp_ragged(g_rag):
     hr, errs = O.ibp(list(g_rag["lr"]), g_rag["shifts"], g_rag["psf_m"], g_rag["hr_init"], 2, 10, 0.5)
     close(hr, g_rag["ibp_10"])

@@ -6,7 +6,8 @@ scripts are loaded by path with importlib -- nothing is copied -- and fed seeded
 synthetic inputs (sr_mi355x.synth) and crops of the reference's committed real inputs.
 Only arrays (inputs + expected outputs) are written; no reference source travels.
 
-    python tools/make_golden.py            # writes tests/golden/
+    python tools/make_golden.py                  # writes tests/golden/
+    python tools/make_golden.py --only-frames    # only frame_zero.npz (round 3)
 """
 import contextlib
 import glob
@@ -51,6 +52,44 @@ def ibp_trace(ref, lr, shifts, psf, init, f, its, step=0.5):
     return out, np.asarray(errs)
 
 
+def frame_goldens(mono, psf_g, psf_m):
+    """delta = 0 cases LARGE enough for the one-launch frame kernel (k_ibp_ztile: H, W >= 128; tiles of 52 x 244 valid pixels, so
+    144 x 280 gives 3 x 2 tiles, all ragged), run through the reference's ibp for the full 80 iterations
+    (mono_cal_target/run_sr.py:190-209, shifts :59-66).  (a) seeded synthetic frames, N = 5 nominal, Gaussian PSF and the
+    reference's measured (non-separable) PSF; (b) a 72 x 140 crop of the committed mono_cal_target frames."""
+    f, h, w = 2, 72, 140
+    nom5 = synth.NOMINAL_5
+    truth = synth.truth_image(h * f, w * f, seed=synth.SEED_TRUTH + 7)
+    lr = make_lr(mono, truth, psf_g, nom5, f, synth.SEED_NOISE + 7)
+    d = dict(truth=truth.astype(np.float32), psf_g=psf_g, psf_m=psf_m, shifts5=np.array(nom5), lr5=lr.astype(np.uint8))
+    saa = mono.shift_and_add(list(lr), nom5, factor=f, order=3)
+    d["saa5"] = saa
+    tr, errs = ibp_trace(mono, lr, nom5, psf_g, saa, f, (1, 10, 80))
+    d["ibp5_1"], d["ibp5_10"], d["ibp5_80"] = tr[1].astype(np.float32), tr[10].astype(np.float32), tr[80]
+    d["ibp5_errors"] = errs
+    hr, errs = quiet(mono.ibp, list(lr), nom5, psf_m, saa.copy(), factor=f, n_iter=80, step=0.5)
+    d["ibp5m_80"], d["ibp5m_errors"] = hr, np.asarray(errs)
+    sess = glob.glob(os.path.join(REF, "mono_cal_target", "data", "*"))[0]
+    frames, shifts = quiet(mono.load_session, sess)
+    y0, x0 = 640, 900
+    crop = [fr[y0:y0 + h, x0:x0 + w].copy() for fr in frames]
+    saa = mono.shift_and_add(crop, shifts, factor=f, order=3)
+    hr, errs = quiet(mono.ibp, crop, shifts, psf_g, saa.copy(), factor=f, n_iter=80, step=0.5)
+    d["real_lr"], d["real_shifts"], d["real_saa"] = np.stack(crop).astype(np.uint8), np.array(shifts), saa
+    d["real_ibp80"], d["real_errors"] = hr, np.asarray(errs)
+    np.savez_compressed(os.path.join(OUT, "frame_zero.npz"), **d)
+
+
+def write_manifest(meta):
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as fp:
+        json.dump({"generated_by": "tools/make_golden.py", "reference": "benedikthoward/ENPH459-Super-Resolution",
+                   "functions": "mono_cal_target/run_sr.py:157-209 (+rgb_cal_target loaders) imported by path",
+                   "versions": meta,
+                   "files": sorted(os.path.basename(p) for p in glob.glob(os.path.join(OUT, "*.npz")))}, fp, indent=1)
+    for p in sorted(glob.glob(os.path.join(OUT, "*.npz"))):
+        print(f"{os.path.basename(p):24s} {os.path.getsize(p) / 1024:8.1f} KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mono = load_ref("mono_cal_target")
@@ -58,6 +97,10 @@ def main():
     psf_g = quiet(mono.make_gaussian_psf)
     psf_m = quiet(mono.load_measured_psf, os.path.join(REF, "calibration_beam_shift", "data"))
     meta = {"scipy": __import__("scipy").__version__, "numpy": np.__version__}
+    frame_goldens(mono, psf_g, psf_m)
+    if "--only-frames" in sys.argv:  # the other files are unchanged since round 1: leave them byte for byte
+        write_manifest(meta)
+        return
 
     # ---------------- C1: f=2, N=4, 32x32 LR -> 64x64 -------------------------------
     f, h, w = 2, 32, 32
@@ -195,13 +238,7 @@ def main():
             wins.append(img[pr - 20:pr + 21, pc - 20:pc + 21].copy())  # 41x41, same arg-max as the full frame
     np.savez_compressed(os.path.join(OUT, "pinholes.npz"), windows=np.stack(wins), psf_m=psf_m)
 
-    with open(os.path.join(OUT, "MANIFEST.json"), "w") as fp:
-        json.dump({"generated_by": "tools/make_golden.py", "reference": "benedikthoward/ENPH459-Super-Resolution",
-                   "functions": "mono_cal_target/run_sr.py:157-209 (+rgb_cal_target loaders) imported by path",
-                   "versions": meta,
-                   "files": sorted(os.path.basename(p) for p in glob.glob(os.path.join(OUT, "*.npz")))}, fp, indent=1)
-    for p in sorted(glob.glob(os.path.join(OUT, "*.npz"))):
-        print(f"{os.path.basename(p):24s} {os.path.getsize(p) / 1024:8.1f} KiB")
+    write_manifest(meta)
 
 
 if __name__ == "__main__":
