@@ -137,103 +137,105 @@ def esf_to_mtf(esf_x, esf_y):
 
 
 def mtf_at_fraction(freq, mtf, fraction=0.5):
-    """Frequency where the MTF first drops below `fraction`, linearly interpolated; nan if it never does or never
-    is above (analysis.ipynb cell 10, psf_mtf_utils.py:165-178)."""
+    """Frequency at which the MTF first falls through `fraction` (linear interpolation between the two samples that bracket
+    the crossing); nan when the curve starts below it or never gets there.  Same values as analysis.ipynb cell 10 /
+    psf_mtf_utils.py:165-178."""
     freq, mtf = np.asarray(freq, dtype=np.float64), np.asarray(mtf, dtype=np.float64)
-    above = mtf >= fraction
-    if not above.any() or above.all():
+    below = mtf < fraction
+    # a downward crossing is an at-or-above sample directly followed by a below sample
+    falls = np.flatnonzero(~below[:-1] & below[1:])
+    if falls.size == 0:
         return np.nan
-    drops = np.where(np.diff(above.astype(int)) == -1)[0]
-    if len(drops) == 0:
-        return np.nan
-    i = drops[0]
-    if abs(mtf[i + 1] - mtf[i]) < 1e-12:
-        return freq[i]
-    return freq[i] + (fraction - mtf[i]) * (freq[i + 1] - freq[i]) / (mtf[i + 1] - mtf[i])
+    lo = falls[0]
+    rise, run = mtf[lo + 1] - mtf[lo], freq[lo + 1] - freq[lo]
+    return freq[lo] if abs(rise) < 1e-12 else freq[lo] + (fraction - mtf[lo]) * run / rise
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # psf_mtf_utils.py
 # ---------------------------------------------------------------------------------------------------------------
 def subpixel_centre(psf):
-    """(row, col) centre of mass of the PSF above 10 % of its peak (psf_mtf_utils.py:67-71)."""
+    """(row, col) first moments of the PSF where it exceeds a tenth of its peak (psf_mtf_utils.py:67-71).  The 2-D moments are
+    taken from the two marginal sums of the thresholded spot."""
     psf = np.asarray(psf, dtype=np.float64)
-    m = np.where(psf > psf.max() * 0.1, psf, 0.0)
-    tot = m.sum()
-    rr, cc = np.mgrid[:psf.shape[0], :psf.shape[1]]
-    return (rr * m).sum() / tot, (cc * m).sum() / tot
+    spot = psf * (psf > 0.1 * psf.max())
+    mass = spot.sum()
+    return float(np.arange(psf.shape[0]) @ spot.sum(axis=1)) / mass, float(np.arange(psf.shape[1]) @ spot.sum(axis=0)) / mass
 
 
 def radial_average(data_2d, center=None, max_radius=None):
-    """Mean over integer-radius rings (truncated distance) around `center` (row, col); returns (radii, profile)
-    (psf_mtf_utils.py:74-95)."""
+    """Ring means: ring k collects the pixels whose distance to `center` (row, col) truncates to k.  Returns (radii, profile);
+    an empty ring gives 0 (psf_mtf_utils.py:74-95).  One histogram pass (np.bincount) for the sums, one for the counts."""
     data_2d = np.asarray(data_2d, dtype=np.float64)
     h, w = data_2d.shape
-    cy, cx = (h / 2.0, w / 2.0) if center is None else center
-    yy, xx = np.mgrid[:h, :w]
-    r_int = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2).astype(int)
+    cy, cx = (0.5 * h, 0.5 * w) if center is None else center
     if max_radius is None:
         max_radius = int(min(cy, cx, h - cy, w - cx))
-    radii = np.arange(0, max_radius)
-    profile = np.zeros(len(radii))
-    for ri in radii:
-        ring = r_int == ri
-        if ring.any():
-            profile[ri] = data_2d[ring].mean()
-    return radii, profile
+    ring = np.hypot(np.arange(w)[None, :] - cx, np.arange(h)[:, None] - cy).astype(np.intp).ravel()
+    nbin = max(int(max_radius), 0)
+    inside = ring < nbin
+    tot = np.bincount(ring[inside], weights=data_2d.ravel()[inside], minlength=nbin)[:nbin]
+    cnt = np.bincount(ring[inside], minlength=nbin)[:nbin]
+    return np.arange(nbin), np.divide(tot, cnt, out=np.zeros(nbin), where=cnt > 0)
+
+
+def _precision_matrix(sigma_x, sigma_y, theta):
+    """Half the inverse covariance of an elliptical Gaussian whose x-axis is turned by theta: R diag(1/2s^2) R^T."""
+    c, s = np.cos(theta), np.sin(theta)
+    rot = np.array([[c, -s], [s, c]])
+    return rot.T @ np.diag([0.5 / sigma_x ** 2, 0.5 / sigma_y ** 2]) @ rot
 
 
 def gauss2d(xy, amp, x0, y0, sigma_x, sigma_y, theta, offset):
-    """Rotated elliptical Gaussian on an offset, flattened (psf_mtf_utils.py:98-106)."""
-    x, y = xy
-    ct, st, s2 = np.cos(theta) ** 2, np.sin(theta) ** 2, np.sin(2 * theta)
-    a = ct / (2 * sigma_x ** 2) + st / (2 * sigma_y ** 2)
-    b = -s2 / (4 * sigma_x ** 2) + s2 / (4 * sigma_y ** 2)
-    c = st / (2 * sigma_x ** 2) + ct / (2 * sigma_y ** 2)
-    dx, dy = x - x0, y - y0
-    return (offset + amp * np.exp(-(a * dx ** 2 + 2 * b * dx * dy + c * dy ** 2))).ravel()
+    """offset + amp exp(-d^T Q d), d = (x - x0, y - y0), flattened: the model of psf_mtf_utils.py:98-106 as a quadratic form
+    on the precision matrix Q."""
+    d = np.stack([np.asarray(xy[0], dtype=np.float64) - x0, np.asarray(xy[1], dtype=np.float64) - y0])
+    q = np.einsum("i...,ij,j...->...", d, _precision_matrix(sigma_x, sigma_y, theta), d)
+    return (offset + amp * np.exp(-q)).ravel()
 
 
 def fit_gaussian_psf(psf):
-    """Bounded least-squares fit of gauss2d; returns (params, fit_image) or (None, None) (psf_mtf_utils.py:109-127).
-    Needs scipy.optimize (as the reference does); raises ImportError without it."""
+    """Bounded least-squares fit of gauss2d to a PSF image, started at its centre of mass with sigma 2 px
+    (psf_mtf_utils.py:109-127; scipy.optimize as there).  Returns (params, model image), or (None, None) if the fit fails."""
     from scipy.optimize import curve_fit
 
     psf = np.asarray(psf, dtype=np.float64)
     h, w = psf.shape
-    y, x = np.mgrid[:h, :w]
+    grid = np.meshgrid(np.arange(w), np.arange(h))  # (x, y)
     cy, cx = subpixel_centre(psf)
-    p0 = [psf.max(), cx, cy, 2.0, 2.0, 0.0, 0.0]
-    lo = [0, 0, 0, 0.3, 0.3, -np.pi, -np.inf]
-    hi = [psf.max() * 2, w, h, w / 2, h / 2, np.pi, psf.max() * 0.5]
+    peak = psf.max()
+    #            amp       x0  y0  sigma_x  sigma_y  theta    offset
+    bounds = {"lo": (0.0, 0.0, 0.0, 0.3, 0.3, -np.pi, -np.inf), "hi": (2.0 * peak, w, h, 0.5 * w, 0.5 * h, np.pi, 0.5 * peak)}
     try:
-        popt, _ = curve_fit(gauss2d, (x, y), psf.ravel(), p0=p0, bounds=(lo, hi), maxfev=20000)
-    except RuntimeError:
-        print("WARNING: Gaussian fit did not converge.", file=sys.stderr)
+        popt, _ = curve_fit(gauss2d, grid, psf.ravel(), p0=(peak, cx, cy, 2.0, 2.0, 0.0, 0.0), bounds=(bounds["lo"], bounds["hi"]),
+                            maxfev=20000)
+    except RuntimeError as exc:
+        print(f"fit_gaussian_psf: no convergence ({exc})", file=sys.stderr)
         return None, None
-    return popt, gauss2d((x, y), *popt).reshape(h, w)
+    return popt, gauss2d(grid, *popt).reshape(h, w)
 
 
 def compute_mtf(psf, pixel_pitch_um=None):
-    """MTF of a PSF: zero-pad (centred) to max(256, shape), normalise the sum, |FFT2| (shifted, peak-normalised), radial
-    average.  Returns (freq, mtf_radial, mtf_2d, freq_label, nyquist) (psf_mtf_utils.py:130-162)."""
+    """Radial MTF of a PSF (psf_mtf_utils.py:130-162): the unit-sum PSF centred in a max(256, shape)^2 field, |FFT2| with the
+    zero frequency in the middle, scaled to peak 1, then ring means.  Returns (freq, mtf_radial, mtf_2d, freq_label, nyquist);
+    frequencies in cycles/pixel, or cycles/mm when the pixel pitch is given."""
     psf = np.asarray(psf, dtype=np.float64)
-    pad = max(256, psf.shape[0], psf.shape[1])
-    big = np.zeros((pad, pad))
-    r0, c0 = (pad - psf.shape[0]) // 2, (pad - psf.shape[1]) // 2
-    big[r0:r0 + psf.shape[0], c0:c0 + psf.shape[1]] = psf
-    s = big.sum()
-    if s > 0:
-        big /= s
-    mtf_2d = np.abs(np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(big))))
-    mx = mtf_2d.max()
-    if mx > 0:
-        mtf_2d /= mx
-    radii, prof = radial_average(mtf_2d, (pad / 2.0, pad / 2.0), pad // 2)
-    freq_cpp = radii.astype(float) / pad
-    if pixel_pitch_um is not None:
-        return freq_cpp / (pixel_pitch_um * 1e-3), prof, mtf_2d, "cycles/mm", 1.0 / (2.0 * pixel_pitch_um * 1e-3)
-    return freq_cpp, prof, mtf_2d, "cycles/pixel", 0.5
+    n = max(256, *psf.shape)
+    before = [(n - e) // 2 for e in psf.shape]
+    field = np.pad(psf, [(b, n - e - b) for b, e in zip(before, psf.shape)])
+    total = field.sum()
+    if total > 0:
+        field = field / total
+    mtf_2d = np.abs(np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(field))))
+    top = mtf_2d.max()
+    if top > 0:
+        mtf_2d = mtf_2d / top
+    rings, mtf_radial = radial_average(mtf_2d, (0.5 * n, 0.5 * n), n // 2)
+    per_px = rings / float(n)
+    if pixel_pitch_um is None:
+        return per_px, mtf_radial, mtf_2d, "cycles/pixel", 0.5
+    pitch_mm = pixel_pitch_um * 1e-3
+    return per_px / pitch_mm, mtf_radial, mtf_2d, "cycles/mm", 0.5 / pitch_mm
 
 
 # ---------------------------------------------------------------------------------------------------------------

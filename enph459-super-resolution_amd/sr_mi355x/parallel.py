@@ -21,6 +21,34 @@ def owner_of(item, world):
     return item % world
 
 
+def _group_rank_world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def map_sharded(fn, n_items, group=None, dst=0):
+    """fn(i) for the items this rank owns; on rank `dst` -> [fn(0), ..., fn(n_items - 1)] in item order (small host objects:
+    one gather_object at the END of the job, the only communication of the sharded mode), None on the other ranks.
+    Without an initialised process group it just loops."""
+    import torch.distributed as dist
+    rank, world = _group_rank_world(group)
+    mine = {i: fn(i) for i in shard_indices(n_items, rank, world)}
+    if world == 1:
+        return [mine[i] for i in range(n_items)]
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(mine, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    if sorted(merged) != list(range(n_items)):
+        raise RuntimeError("sharding lost or duplicated items")
+    return [merged[i] for i in range(n_items)]
+
+
 def default_compute(lr, shifts_yx, kernel, factor, n_iter, step):
     """One item on this rank's GPU through libsrx: SAA then IBP -> (hr float64 numpy, errors list)."""
     from . import api
@@ -30,29 +58,11 @@ def default_compute(lr, shifts_yx, kernel, factor, n_iter, step):
 
 def reconstruct_sharded(items, shifts_yx, kernel, factor=2, n_iter=80, step=0.5, compute=None, group=None, dst=0):
     """items: list of LR stacks [N, h, w] (every rank passes the same list; only owned ones are touched).
-
-    Returns, on rank `dst`, a list with one (hr, errors) per item in the original order; None elsewhere.
-    Without an initialised process group it just loops (world = 1).
-    """
-    import torch.distributed as dist
+    Returns, on rank `dst`, a list with one (hr, errors) per item in the original order; None elsewhere."""
     compute = compute or default_compute
-    if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-    else:
-        rank, world = 0, 1
-    mine = {}
-    for i in shard_indices(len(items), rank, world):
+
+    def one(i):
         hr, errs = compute(items[i], shifts_yx, kernel, factor, n_iter, step)
-        mine[i] = (np.asarray(hr), [float(e) for e in errs])
-    if world == 1:
-        return [mine[i] for i in range(len(items))]
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object(mine, gathered, dst=dst, group=group)
-    if rank != dst:
-        return None
-    merged = {}
-    for part in gathered:
-        merged.update(part)
-    if sorted(merged) != list(range(len(items))):
-        raise RuntimeError("sharding lost or duplicated items")
-    return [merged[i] for i in range(len(items))]
+        return np.asarray(hr), [float(e) for e in errs]
+
+    return map_sharded(one, len(items), group=group, dst=dst)

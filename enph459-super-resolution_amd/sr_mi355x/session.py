@@ -211,12 +211,27 @@ class Prefetcher:
             return out
         return self._load(item)
 
+    @staticmethod
+    def _adopt(obj):
+        """The tensors were allocated under the loader's side stream and are consumed on the caller's: tell the caching allocator,
+        so that a block freed by the consumer is not handed to the next prefetch while the compute stream still reads it."""
+        import torch
+        if isinstance(obj, torch.Tensor):
+            if obj.is_cuda:
+                obj.record_stream(torch.cuda.current_stream())
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                Prefetcher._adopt(o)
+
     def __iter__(self):
-        for k, item in enumerate(self._items):
-            cur = self._next.result()
-            self._next = self._pool.submit(self._guarded, self._items[k + 1]) if k + 1 < len(self._items) else None
-            yield item, cur
-        self._pool.shutdown()
+        try:
+            for k, item in enumerate(self._items):
+                cur = self._next.result()
+                self._next = self._pool.submit(self._guarded, self._items[k + 1]) if k + 1 < len(self._items) else None
+                self._adopt(cur)
+                yield item, cur
+        finally:  # also when the consumer raises or stops early
+            self._pool.shutdown(wait=True, cancel_futures=True)
 
 
 PNG_COMPRESS_LEVEL = 1  # zlib level of the PNGs written (PIL's default is 6: ~4x the encode time for ~10 % smaller files; lossless either way)
@@ -332,32 +347,49 @@ def load_session(session_dir, kind):
 
 def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None, row_bands=False):
     """The reference's outer loop (mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301) over the sessions this
-    rank owns (session i -> rank i mod world, parallel.shard_indices: independent items, no collective), with the PNG decode
-    and upload of session k + 1 overlapped with the device work of session k.  -> output directories written by this rank.
+    rank owns (session i -> rank i mod world, parallel.map_sharded: independent items, no data-path collective), with the PNG
+    decode and upload of session k + 1 overlapped with the device work of session k.  -> output directories written: by every
+    rank's sessions, in session order, on rank 0 (one gather of the directory names when the job ends); this rank's own elsewhere.
     row_bands: the other way to use several GPUs -- every rank walks ALL sessions and each image is split into row bands."""
     from . import parallel
     if row_bands and kind not in ("mono_cal_target", "rgb_cal_target"):
         raise ValueError("row_bands is for the one-image-per-session kinds (the barcode kinds batch their reps instead)")
-    mine = list(sessions) if row_bands else [sessions[i] for i in parallel.shard_indices(len(sessions), rank, world)]
+    owned = list(range(len(sessions))) if row_bands else parallel.shard_indices(len(sessions), rank, world)
     say = print if verbose else (lambda *a, **k: None)
-    written = []
 
-    def load(sdir):
-        name = os.path.basename(os.path.normpath(sdir))
+    def load(i):
+        name = os.path.basename(os.path.normpath(sessions[i]))
         if kind in ("mono_cal_target", "rgb_cal_target") and os.path.exists(os.path.join(output_base, name, "done.flag")):
             return None  # process_session will skip it: do not decode
-        return load_session(sdir, kind)
+        return load_session(sessions[i], kind)
 
-    for k, (sdir, loaded) in enumerate(Prefetcher(mine, load), 1):
-        say(f"\n[rank {rank}: {k}/{len(mine)}] {os.path.basename(sdir)}")
-        out = process_session(sdir, psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded, flush=on_written is not None,
-                              row_bands=row_bands)
+    feed = iter(Prefetcher(owned, load))
+    count = [0]
+
+    def one(i):
+        j, loaded = next(feed)  # the prefetcher walks the owned sessions in the same order map_sharded does
+        assert j == i
+        count[0] += 1
+        say(f"\n[rank {rank}: {count[0]}/{len(owned)}] {os.path.basename(sessions[i])}")
+        out = process_session(sessions[i], psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded,
+                              flush=on_written is not None, row_bands=row_bands)
         if on_written:
             for d in out:
                 on_written(d)
-        written += out
-    flush_writes()  # the PNG encodes of session k ran beside the device work of session k + 1
-    return written
+        return out
+
+    try:
+        import torch.distributed as dist
+        if row_bands or world == 1 or not (dist.is_available() and dist.is_initialized()):
+            per_session = [one(i) for i in owned]  # (a caller playing one rank of several without a process group gets its own share)
+        else:
+            per_session = parallel.map_sharded(one, len(sessions))
+    finally:
+        feed.close()  # shuts the decode thread down, also when a session raised
+        flush_writes()  # the PNG encodes of session k ran beside the device work of session k + 1
+    if per_session is None:  # not rank 0 of a sharded job
+        return []
+    return [d for out in per_session for d in out]
 
 
 def write_metrics(out_dir, factor=UPSAMPLE_FACTOR):
@@ -398,26 +430,24 @@ def discover_sessions(data_dir, kind):
 # measured PSF (load_measured_psf, mono_cal_target/run_sr.py:114-152): host side, once per run, tiny
 # ---------------------------------------------------------------------------------------------------------
 def psf_from_pinhole_images(images, halfwidth=PSF_HALFWIDTH):
-    """images: iterable of 2-D arrays (pinhole frames).  Peak-aligned mean of +-(halfwidth+6) crops, central
-    (2*halfwidth+1)^2 window, minus the mean of its four 3x3 corner blocks, clipped at 0, normalised to sum 1."""
-    margin = halfwidth + 6
-    patches = []
-    for img in images:
-        img = np.asarray(img, dtype=np.float64)
-        pr, pc = np.unravel_index(img.argmax(), img.shape)
-        R = margin
-        if pr < R or pr + R + 1 > img.shape[0] or pc < R or pc + R + 1 > img.shape[1]:
-            continue  # peak too close to the edge (the reference skips these)
-        patches.append(img[pr - R:pr + R + 1, pc - R:pc + R + 1].copy())
-    if not patches:
+    """images: iterable of 2-D arrays (pinhole frames).  The brightest pixel of every frame is brought to the centre of a
+    (2 (halfwidth + 6) + 1)^2 window (frames whose window would leave the image are dropped); the windows' mean is cut to its
+    central (2 halfwidth + 1)^2, the mean of the four 3 x 3 corner blocks is taken off as background, negatives are clipped and
+    the kernel normalised to sum 1 (load_measured_psf, mono_cal_target/run_sr.py:114-152)."""
+    reach, side = halfwidth + 6, 2 * halfwidth + 1
+    span = np.arange(-reach, reach + 1)
+    windows = []
+    for frame in images:
+        frame = np.asarray(frame, dtype=np.float64)
+        peak = np.array(np.unravel_index(np.argmax(frame), frame.shape))
+        if np.all(peak >= reach) and np.all(peak + reach < np.array(frame.shape)):
+            windows.append(frame[np.ix_(peak[0] + span, peak[1] + span)])
+    if not windows:
         raise FileNotFoundError("no usable pinhole image")
-    avg = np.mean(patches, axis=0)
-    R = margin
-    k = avg[R - halfwidth:R + halfwidth + 1, R - halfwidth:R + halfwidth + 1].copy()
-    corners = np.concatenate([k[:3, :3].ravel(), k[:3, -3:].ravel(), k[-3:, :3].ravel(), k[-3:, -3:].ravel()])
-    k -= np.mean(corners)
-    k = np.clip(k, 0, None)
-    return k / k.sum()
+    core = np.stack(windows).mean(axis=0)[6:6 + side, 6:6 + side]
+    edge = np.r_[0:3, side - 3:side]  # the three outermost rows / columns on either side
+    core = np.maximum(core - core[np.ix_(edge, edge)].mean(), 0.0)
+    return core / core.sum()
 
 
 def load_measured_psf(psf_dir):
