@@ -35,6 +35,13 @@ namespace patch {
 #ifndef SRX_ADDTID
 #define SRX_ADDTID 1
 #endif
+#ifndef SRX_M0_NOP
+#define SRX_M0_NOP "s_nop 0\n\t"  // the ISA asks for one wait state between a scalar write of M0 and an LDS add-TID instruction, and inside
+                                  // an asm block nobody inserts it.  Without it the first store of a block sometimes went out with the M0 of
+                                  // before (round 3: k_ibp_ztile's 7 x 7 form, one row of one wave wrong in 7 of 40 calls, always behind the
+                                  // tile that sums the previous iteration's MSE partials; tools/stress_determinism.py, tests/test_gpu_parity.py::
+                                  // test_frame_kernel_is_deterministic).  "" reproduces it.
+#endif
 #ifndef SRX_TRANSPOSE_DEF
 #define SRX_TRANSPOSE_DEF 1
 #endif
@@ -280,7 +287,7 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
         // than the 16 bits older ISA documents name -- with the address masked to 16 bits waves 8..15 wrote into the wrong regions and
         // tests/test_gpu_parity.py::test_patch_kernel_vs_oracle failed at once).
         static_assert(TSD * 4 == 264, "offsets below");
-        asm volatile("s_mov_b32 m0, %16\n\t"
+        asm volatile("s_mov_b32 m0, %16\n\t" SRX_M0_NOP
                      "ds_write_addtid_b32 %0 offset:0\n\t"
                      "ds_write_addtid_b32 %1 offset:264\n\t"
                      "ds_write_addtid_b32 %2 offset:528\n\t"
@@ -298,7 +305,7 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
                      "ds_write_addtid_b32 %14 offset:3696\n\t"
                      "ds_write_addtid_b32 %15 offset:3960\n\t"
                      :: "v"(a[32 * h + 0]), "v"(a[32 * h + 1]), "v"(a[32 * h + 2]), "v"(a[32 * h + 3]), "v"(a[32 * h + 4]), "v"(a[32 * h + 5]), "v"(a[32 * h + 6]), "v"(a[32 * h + 7]), "v"(a[32 * h + 8]), "v"(a[32 * h + 9]), "v"(a[32 * h + 10]), "v"(a[32 * h + 11]), "v"(a[32 * h + 12]), "v"(a[32 * h + 13]), "v"(a[32 * h + 14]), "v"(a[32 * h + 15]), "s"(m0v) : "memory", "m0");
-        asm volatile("s_mov_b32 m0, %16\n\t"
+        asm volatile("s_mov_b32 m0, %16\n\t" SRX_M0_NOP
                      "ds_write_addtid_b32 %0 offset:4224\n\t"
                      "ds_write_addtid_b32 %1 offset:4488\n\t"
                      "ds_write_addtid_b32 %2 offset:4752\n\t"

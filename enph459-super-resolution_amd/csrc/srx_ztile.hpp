@@ -83,6 +83,7 @@ struct ZTabs {
     const unsigned *CM;      // [B][WP / 2][HP]: both as 16 bits per pixel (C << 12 | M), two columns per word; valid where cmok[b]
     const int *cmok;         // [B]: every M of the item is an integer < 4096 and every C < 16 (uint8 frames, at most 15 per pixel)
     const patch::AxisW *aw;  // [2]: y, x (kb, kt un-scaled here: kq = 1)
+    const float *k2;         // [2][7][8]: a PSF that is not rank 1 -- correlation weights of the blur, then of the adjoint blur rows padded to 8
     const unsigned *nrec;    // [NT] cnt | cu << 8
     const uint4 *nent;       // [ngrp][NT] four entries rho_y | rho_x << 16 (natural, clamped)
     const float2 *Mn;        // [B][NT] (M, Mu)
@@ -106,7 +107,9 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
         return false;
     fused::Kernel7<float> kc;
     fused::make_kernel7<float>(k, kh, kw, false, kc);
-    return kc.separable && axis_ok(py, N, f) && axis_ok(px, N, f);
+    // a PSF that is not rank 1 (the reference's --psf measured, mono_cal_target/run_sr.py:114-152) runs both 7 x 7 blurs in row
+    // layout, rows = lanes: one block row per tile
+    return (kc.separable || NSY == 1) && axis_ok(py, N, f) && axis_ok(px, N, f);
 }
 
 // ---- once per call -----------------------------------------------------------------------------------------------------
@@ -218,6 +221,15 @@ __global__ void __launch_bounds__(256)
     Mn[(size_t)b * NT + T] = make_float2(Mg[((size_t)b * Hg + gy + 13) * Wg + gx + 13], Mu[(size_t)b * NB + ni]);
 }
 
+struct K2Tab {
+    float v[112];
+};
+__global__ void k_ztile_k2(K2Tab t, float *__restrict__ dst)
+{
+    if (threadIdx.x < 112)
+        dst[threadIdx.x] = t.v[threadIdx.x];
+}
+
 // MSE trace: sum of the tiles' partial sums of one iteration, fixed order.  grid B, block 256
 __global__ void __launch_bounds__(256)
     k_ztile_trace(const double *__restrict__ epart, int ntiles, const double *__restrict__ Vtot, double scale, double *__restrict__ errors, int stride)
@@ -230,6 +242,85 @@ __global__ void __launch_bounds__(256)
         *out *= scale;
 }
 
+// ---- 7 x 7 correlation with a PSF that is not rank 1, on a block in ROW layout (lane = row, a[j] = column j) ------------------
+// out[y][x] = sum_{u, v} k[u][v] in[y - 3 + u][x - 3 + v].  The v direction runs along the registers (three columns from either
+// neighbour block through the waves' LDS slots, as blur_block); the u direction runs along the LANES: t_u = sum_v k[u][v] in[.][x - 3 + v]
+// is formed by every lane for its own row and the seven t_u are combined by a Horner scheme of one-lane wave shifts,
+//   out = t_3 + up(t_2 + up(t_1 + up(t_0))) + dn(t_4 + dn(t_5 + dn(t_6))),   up(v)[lane] = v[lane - 1], dn(v)[lane] = v[lane + 1]
+// (DPP wave_shr:1 / wave_shl:1, zero shifted in: rows beyond the block are outside every dependency cone that ends in a stored
+// pixel, exactly as in the separable form).  Two adjacent COLUMNS advance as one packed pair (v_pk_fma_f32: two fmas per
+// instruction): the weight is one scalar register broadcast to both halves, the samples are the register pair (x, x + 1) -- the
+// window is kept twice, once for each pair alignment.  A pixel costs 24.5 packed fmas + 6 shifts + 3 packed adds instead of 49 + 6 + 6.
+// (tools/microbench/pk_sgpr.hip: a packed fp32 instruction honours op_sel on a scalar pair, so a weight may sit in either half of an
+// aligned pair; wave_shr:1 / wave_shl:1 move whole-wave, lane i reads lane i - 1 / i + 1.  tools/microbench/dpp_after_pk.hip: one wait
+// state between a packed producer and a DPP read is enough, the compiler leaves two.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_up(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float lane_dn(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
+__device__ __forceinline__ f2 lane_up(f2 v) { return (f2){lane_up(v.x), lane_up(v.y)}; }
+__device__ __forceinline__ f2 lane_dn(f2 v) { return (f2){lane_dn(v.x), lane_dn(v.y)}; }
+
+__device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext, int s6,
+                                             int lane, const float *w56)
+{
+    Rown[s6 + lane] = a[0];
+    Rown[s6 + 64 + lane] = a[1];
+    Rown[s6 + 128 + lane] = a[2];
+    Rown[s6 + 192 + lane] = a[61];
+    Rown[s6 + 256 + lane] = a[62];
+    Rown[s6 + 320 + lane] = a[63];
+    f8 kw[7];  // kw[u][v]
+#pragma unroll
+    for (int u = 0; u < 7; u++)
+        kw[u] = sload8(w56 + 8 * u);
+    __syncthreads();
+    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+    if (!first)
+        hl[0] = Rprev[s6 + 192 + lane], hl[1] = Rprev[s6 + 256 + lane], hl[2] = Rprev[s6 + 320 + lane];
+    if (!last)
+        hr[0] = Rnext[s6 + lane], hr[1] = Rnext[s6 + 64 + lane], hr[2] = Rnext[s6 + 128 + lane];
+    // in place, NB outputs at a time (the window of NB + 6 inputs and the three old values the next group still needs are live)
+    constexpr int NB = 4;
+    float c0 = hl[0], c1 = hl[1], c2 = hl[2];
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += NB) {
+        float w[NB + 6];
+        w[0] = c0, w[1] = c1, w[2] = c2;
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            w[3 + j] = a[j0 + j];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            w[NB + 3 + j] = j0 + NB + j < 64 ? a[j0 + NB + j] : hr[j];
+        c0 = w[NB], c1 = w[NB + 1], c2 = w[NB + 2];
+        f2 pw[NB + 5];  // (x, x + 1) for every x of the window
+#pragma unroll
+        for (int m = 0; m < NB + 5; m++)
+            pw[m] = (f2){w[m], w[m + 1]};
+#pragma unroll
+        for (int j = 0; j < NB; j += 2) {
+            f2 t[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                t[u] = (f2){kw[u][0], kw[u][0]} * pw[j];
+#pragma unroll
+                for (int v = 1; v < 7; v++)
+                    t[u] = __builtin_elementwise_fma((f2){kw[u][v], kw[u][v]}, pw[j + v], t[u]);
+            }
+            f2 up = t[1] + lane_up(t[0]);
+            up = t[2] + lane_up(up);
+            f2 dn = t[5] + lane_dn(t[6]);
+            dn = t[4] + lane_dn(dn);
+            const f2 o = (t[3] + lane_up(up)) + lane_dn(dn);
+            a[j0 + j] = o.x, a[j0 + j + 1] = o.y;
+            // an opaque use right here: left alone, the last two adds of every pixel are sunk to the block that first reads a[] -- three
+            // live values per pixel instead of one across the whole blur (192 registers: 25 spilled pairs per lane)
+            asm volatile("" : "+v"(a[j0 + j]), "+v"(a[j0 + j + 1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // =========================================================================================================================
 // One iteration on one tile.  grid (tiles_x, tiles_y, B), block 256 NSY: wave (s, u) owns the 64 x 64 block at region rows 64 s,
 // columns 64 u (the block layouts of k_ibp_patch; NSY = 1: four waves side by side).
@@ -237,6 +328,7 @@ __global__ void __launch_bounds__(256)
 // own (or outside the image) goes to the plane's trash row / out of the buffer's range.  epart: this iteration's per-tile MSE
 // partial sums (or null); eprev: the previous iteration's, which one interior tile adds up into err_prev[item * err_stride].
 // =========================================================================================================================
+template <bool SEP>
 __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart,
                 const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
@@ -284,19 +376,22 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
         const int i = SRX_ZTILE_LOAD_EDGES_FIRST ? (k < 2 ? k : (k < 4 ? 28 + k : k - 2)) : k;  // pairs 0, 1, 30, 31 first
         ld2(i, a[2 * i], a[2 * i + 1]);
     }
-#if SRX_ZTILE_HOLD
-    float hold[64];
+    constexpr bool HOLD = SRX_ZTILE_HOLD;
+    float hold[HOLD ? 64 : 1];
+    if constexpr (HOLD) {
 #pragma unroll
-    for (int i = 0; i < 64; i++)
-        hold[i] = a[i];
-#endif
+        for (int i = 0; i < 64; i++)
+            hold[i] = a[i];
+    }
     // blur down the columns (three rows from the blocks above / below; zero at the region's edge: those outputs are outside
     // every dependency cone that ends in a stored pixel)
     SRX_PSTAMP(1);
     auto vblur = [&](const f8 k) { patch::blur_block(a, s == 0, s == NSY - 1, Rown, Rup, Rdn, patch::SLOT0, lane, k); };
-    vblur(sload8(awy));
-    SRX_PSTAMP(2);
-    __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
+    if (SEP) {
+        vblur(sload8(awy));
+        SRX_PSTAMP(2);
+        __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
+    }
     SRX_PSTAMP(3);
     patch::transpose64(a, r, Rown, lane);
     SRX_PSTAMP(4);
@@ -321,7 +416,10 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     if (cmok) {
         ldcm(cma, 0);
     }
-    patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, sload8(awx));
+    if (SEP)
+        patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, sload8(awx));
+    else
+        blur2d_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, tb.k2);
     SRX_PSTAMP(5);
     float sq = 0.f;
     // ---- near band (tiles on the top / left image edge): strips of b, the listed sums, strips of G
@@ -458,7 +556,10 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
         if (lane == 0)
             part[wave] = ws;
     }
-    patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, sload8(awx + 8));
+    if (SEP)
+        patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, sload8(awx + 8));
+    else
+        blur2d_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, tb.k2 + 56);
     if (epart && tid == 0) {
         double t = 0.0;
 #pragma unroll
@@ -471,7 +572,8 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     patch::transpose64(r, a, Rown, lane);
     SRX_PSTAMP(9);
     // ================= stage C: column layout again =================
-    vblur(sload8(awy + 8));
+    if (SEP)
+        vblur(sload8(awy + 8));
     SRX_PSTAMP(10);
     // ---- update and store.  Rows this tile does not own (or below the image) go to the trash row; columns it does not own
     // (or right of the image) get an offset beyond the buffer's range, which drops the store.
@@ -480,12 +582,11 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     const int vst = (cc >= HALO && cc < RG - HALO && pc0 + cc - HALO < W) ? vc0 : 0x7ffffff0;
     // loads and arithmetic first, every store at the very end: vmcnt counts loads and stores in one order, so a wait for a batch of
     // loads behind a batch of stores would also wait for those stores to complete
-#if SRX_ZTILE_HOLD
+    if constexpr (HOLD) {
 #pragma unroll
-    for (int i = 0; i < 64; i++)
-        a[i] = __builtin_amdgcn_fmed3f(fmaf(a[i], za.sn, hold[i]), 0.f, 255.f);
-#else
-    {
+        for (int i = 0; i < 64; i++)
+            a[i] = __builtin_amdgcn_fmed3f(fmaf(a[i], za.sn, hold[i]), 0.f, 255.f);
+    } else {
         float hv[16], hw[16];
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -505,7 +606,6 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#endif
     SRX_PSTAMP(11);
 #pragma unroll
     for (int k = 0; k < 32; k++) {
@@ -525,7 +625,7 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
     const size_t ty = cdiv(H, VTY), tx = cdiv(W, VT), HP = ty * VTY + 2 * HALO, WP = tx * VT + 2 * HALO;
     return align_up((size_t)B * HP * WP * 4) + 2 * align_up((size_t)B * (HP + 2) * WP * 4) + align_up(HP * WP * 4) +
            align_up((size_t)B * (WP / 2) * HP * 4) + align_up((size_t)B * 4) +
-           align_up(2 * sizeof(patch::AxisW)) + align_up(NT * 4) + align_up(ngrp * NT * 16) + align_up((size_t)B * NT * 8) +
+           align_up(2 * sizeof(patch::AxisW)) + align_up(112 * 4) + align_up(NT * 4) + align_up(ngrp * NT * 16) + align_up((size_t)B * NT * 8) +
            2 * align_up((size_t)B * ty * tx * 8);
 }
 
@@ -557,6 +657,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
     unsigned *CM = ar.take<unsigned>((size_t)B * (WP / 2) * HP);
     int *cmok = ar.take<int>(B);
     patch::AxisW *aw = ar.take<patch::AxisW>(2);
+    float *k2 = ar.take<float>(112);
     unsigned *nrec = ar.take<unsigned>(NT);
     uint4 *nent = ar.take<uint4>((size_t)za.ngrp * NT);
     float2 *Mn = ar.take<float2>((size_t)B * NT);
@@ -570,6 +671,15 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
     }
     hipLaunchKernelGGL(patch::k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
+    const bool sep = kc.separable && kt.separable;
+    if (!sep) {
+        K2Tab kv;
+        for (int u = 0; u < 7; u++)
+            for (int v = 0; v < 8; v++)
+                kv.v[8 * u + v] = v < 7 ? kc.k[7 * u + v] : 0.f, kv.v[56 + 8 * u + v] = v < 7 ? kt.k[7 * u + v] : 0.f;
+        hipLaunchKernelGGL(k_ztile_k2, dim3(1), dim3(128), 0, st, kv, k2);
+        SRX_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_ztile_prep, dim3(cdiv(WP, 32), cdiv(HP, 32), B + 1), dim3(32, 8), 0, st, Mg, Cg, B, H, W, HP, WP, za.nby, za.nbx, Mt, Ct);
     SRX_CHECK_LAUNCH();
     if (hipMemsetAsync(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
@@ -587,7 +697,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
         hipLaunchKernelGGL(k_ztile_near_m, dim3(cdiv(NT, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, za, NT, Mn);
         SRX_CHECK_LAUNCH();
     }
-    ZTabs tb{Mt, Ct, CM, cmok, aw, nrec, nent, Mn};
+    ZTabs tb{Mt, Ct, CM, cmok, aw, k2, nrec, nent, Mn};
     // ping-pong between the two padded planes (a tile reads its neighbours' pixels of the previous iteration)
     const dim3 grid(za.tiles_x, za.tiles_y, B);
     for (int it = 0; it < n_iter; it++) {
@@ -595,8 +705,12 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
         float *dst = (it & 1) ? s0 : s1;
         double *ep = errors ? ((it & 1) ? ep1 : ep0) : nullptr;
         const double *eprev = errors && it > 0 ? ((it & 1) ? ep0 : ep1) : nullptr;  // the partial sums iteration it - 1 left
-        SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale, errors ? errors + it - 1 : nullptr,
-                   n_iter);
+        if (sep)
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<true>, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale,
+                       errors ? errors + it - 1 : nullptr, n_iter);
+        else
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<false>, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale,
+                       errors ? errors + it - 1 : nullptr, n_iter);
     }
     if (errors) {
         hipLaunchKernelGGL(k_ztile_trace, dim3(B), dim3(256), 0, st, ((n_iter - 1) & 1) ? ep1 : ep0, ntiles, Vtot, scale, errors + n_iter - 1, n_iter);
