@@ -257,8 +257,6 @@ __global__ void __launch_bounds__(256)
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lane_up(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
 __device__ __forceinline__ float lane_dn(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
-__device__ __forceinline__ f2 lane_up(f2 v) { return (f2){lane_up(v.x), lane_up(v.y)}; }
-__device__ __forceinline__ f2 lane_dn(f2 v) { return (f2){lane_dn(v.x), lane_dn(v.y)}; }
 
 __device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext, int s6,
                                              int lane, const float *w56)
@@ -307,11 +305,19 @@ __device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool la
                 for (int v = 1; v < 7; v++)
                     t[u] = __builtin_elementwise_fma((f2){kw[u][v], kw[u][v]}, pw[j + v], t[u]);
             }
-            f2 up = t[1] + lane_up(t[0]);
-            up = t[2] + lane_up(up);
-            f2 dn = t[5] + lane_dn(t[6]);
-            dn = t[4] + lane_dn(dn);
-            const f2 o = (t[3] + lane_up(up)) + lane_dn(dn);
+            // (scalar adds: each folds its shift into one v_add_f32_dpp; as packed adds the shifts stay separate moves)
+            float ox, oy;
+            {
+                float up = t[1].x + lane_up(t[0].x), dn = t[5].x + lane_dn(t[6].x);
+                up = t[2].x + lane_up(up), dn = t[4].x + lane_dn(dn);
+                ox = (t[3].x + lane_up(up)) + lane_dn(dn);
+            }
+            {
+                float up = t[1].y + lane_up(t[0].y), dn = t[5].y + lane_dn(t[6].y);
+                up = t[2].y + lane_up(up), dn = t[4].y + lane_dn(dn);
+                oy = (t[3].y + lane_up(up)) + lane_dn(dn);
+            }
+            const f2 o = {ox, oy};
             a[j0 + j] = o.x, a[j0 + j + 1] = o.y;
             // an opaque use right here: left alone, the last two adds of every pixel are sunk to the block that first reads a[] -- three
             // live values per pixel instead of one across the whole blur (192 registers: 25 spilled pairs per lane)
