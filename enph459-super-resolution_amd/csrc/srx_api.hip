@@ -313,10 +313,7 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
         return SRX_E_UNSUPPORTED;
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
         if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
-            g_last_path = (!(flags & SRX_FLAG_TILES) && patch::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)) ? "patch"
-                          : ztile::eligible((int)sizeof(T), N, H, W, sh, k, kh, kw, f)                              ? "ztile"
-                                                                                                                    : "mosaic";
-            return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
+            return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st, &g_last_path);
         }
         g_last_path = "fused";
         return fused::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);
@@ -457,6 +454,23 @@ size_t srx_ibp_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W,
     if (flags & SRX_FLAG_COMPOSED)
         return a;
     return a > b ? a : b;
+}
+
+/* the same with the shift table and the PSF at hand: what THIS call will carve (a batch of 256 x 256 patches at a common fraction
+ * needs no tile planes, a delta = 0 frame no patch tables ...), never more than srx_ibp_workspace_bytes */
+size_t srx_ibp_workspace_bytes_for(int eb, int B, int N, int h, int w, int H, int W, int f, const double *sh, const double *k, int kh,
+                                   int kw, unsigned flags)
+{
+    const size_t bound = srx_ibp_workspace_bytes(eb, B, N, h, w, H, W, f, flags);
+    if (!sh || !k || N <= 0 || N > SRX_MAX_FRAMES || (flags & (SRX_FLAG_COMPOSED | SRX_FLAG_PER_FRAME)))
+        return bound;
+    if (B > SRX_MAX_BATCH_PER_LAUNCH)
+        B = SRX_MAX_BATCH_PER_LAUNCH;
+    CallFlags cf(flags);
+    if (!(fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)))
+        return bound;
+    const size_t need = mosaic::ibp_ws_for(eb, B, N, H, W, sh, k, kh, kw, f);
+    return need < bound ? need : bound;
 }
 
 int srx_interleave4_u8(const uint8_t *frames, int B, int h, int w, uint8_t *out, srx_stream_t s)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -93,11 +94,14 @@ struct ProfRecord {
     hipEvent_t a, b;
 };
 
-// Thread-safe: every method takes the mutex, a launch owns the record index begin() returned, and events are pooled (a
-// cleared log returns its events to the pool instead of destroying them, so a long profiled run creates each event once).
+// Thread-safe: every method takes the mutex; `on` is atomic (SRX_LAUNCH reads it without the lock); a launch owns the handle
+// begin() returned -- the record's index tagged with the log's generation, so that an end() behind a clear() of another thread is
+// dropped instead of landing in a recycled slot -- and events are pooled (a cleared log returns its events to the pool instead of
+// destroying them, so a long profiled run creates each event once).
 struct Profiler {
     std::mutex mu;
-    bool on = false;  // read without the lock by SRX_LAUNCH (a benign race: a launch is either timed or not)
+    std::atomic<bool> on{false};
+    unsigned gen = 0;  // bumped by clear()
     std::vector<ProfRecord> rec;
     std::vector<hipEvent_t> pool;
     hipEvent_t take()
@@ -111,21 +115,27 @@ struct Profiler {
         }
         return e;
     }
-    long begin(int id, hipStream_t st)
+    long long begin(int id, hipStream_t st)
     {
         std::lock_guard<std::mutex> g(mu);
         ProfRecord r{id, take(), take()};
-        if (!r.a || !r.b)
+        if (!r.a || !r.b) {  // a partial pair goes back to the pool
+            if (r.a)
+                pool.push_back(r.a);
+            if (r.b)
+                pool.push_back(r.b);
             return -1;
+        }
         (void)hipEventRecord(r.a, st);
         rec.push_back(r);
-        return (long)rec.size() - 1;
+        return ((long long)gen << 32) | (long long)(rec.size() - 1);
     }
-    void end(long i, hipStream_t st)
+    void end(long long h, hipStream_t st)
     {
         std::lock_guard<std::mutex> g(mu);
-        if (i >= 0 && (size_t)i < rec.size())
-            (void)hipEventRecord(rec[(size_t)i].b, st);
+        const size_t i = (size_t)(h & 0xffffffffll);
+        if (h >= 0 && (unsigned)(h >> 32) == gen && i < rec.size())
+            (void)hipEventRecord(rec[i].b, st);
     }
     void clear()
     {
@@ -135,6 +145,7 @@ struct Profiler {
             pool.push_back(r.b);
         }
         rec.clear();
+        gen = (gen + 1) & 0x7fffffffu;
     }
 };
 
@@ -144,7 +155,7 @@ Profiler &profiler();
 #define SRX_LAUNCH(ID, KERNEL, GRID, BLOCK, SHMEM, ST, ...)                   \
     do {                                                                      \
         srx::Profiler &_pf = srx::profiler();                                 \
-        const long _pi = _pf.on ? _pf.begin(ID, ST) : -1;                     \
+        const long long _pi = _pf.on.load(std::memory_order_relaxed) ? _pf.begin(ID, ST) : -1;                     \
         hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, ST, __VA_ARGS__);      \
         if (_pi >= 0)                                                         \
             _pf.end(_pi, ST);                                                 \

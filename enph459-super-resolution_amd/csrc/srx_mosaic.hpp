@@ -1047,38 +1047,85 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
+// Workspace of one call.  At most one of the three implementations runs, and each carves only what it needs behind the tables every
+// one of them uses (M, C, Mu, the tap tables, the near-band lists):
+//   tiles : the blurred plane, G, per-tile MSE partials      patch : srx_patch.hpp's operand planes and tables
+//   ztile : srx_ztile.hpp's padded state / operand planes and tables
+enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2 };
+
+static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
-    const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
+    if (eb == 4 && !(call_flags() & SRX_FLAG_TILES) && patch::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_PATCH;
+    if (ztile::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_ZTILE;
+    return IMPL_TILES;
+}
+
+static inline size_t ws_common(int eb, int B, int N, int H, int W)
+{
+    const size_t Hg = H + 2 * SRX_NPAD + 3, Wg = W + 2 * SRX_NPAD + 3;
     const size_t NBmax = 20 * (Hg + Wg);  // near band: PB <= 18 rows + 18 columns of the plane
     const size_t NS = (N + 3) & ~3;
-    return align_up((size_t)B * Hp * Wp * eb) + 2 * align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) +
-           align_up((size_t)B * NBmax * eb) + 2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) +
-           align_up((size_t)B * sizeof(double)) + align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int)) +
-           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double)) +
-           (eb == 4 && H == 256 && W == 256 ? patch::tabs_bytes(B, N) : 0) +  // srx_patch.hpp's tables
-           (eb == 4 && H >= 128 && W >= 128 ? ztile::tabs_bytes(B, N, H, W) : 0);  // srx_ztile.hpp's planes and tables
+    return align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) + align_up((size_t)B * NBmax * eb) +
+           2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double)) +
+           align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int));
+}
+
+static inline size_t ws_impl(Impl im, int eb, int B, int N, int H, int W)
+{
+    const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
+    if (im == IMPL_PATCH)
+        return patch::tabs_bytes(B, N);
+    if (im == IMPL_ZTILE)
+        return ztile::tabs_bytes(B, N, H, W);
+    return align_up((size_t)B * Hp * Wp * eb) + align_up((size_t)B * Hg * Wg * eb) +
+           align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
+}
+
+// without the shift table and the PSF the implementation is not known: the largest of those the shape admits
+static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
+{
+    size_t m = ws_impl(IMPL_TILES, eb, B, N, H, W);
+    if (eb == 4 && H == 256 && W == 256)
+        m = std::max(m, ws_impl(IMPL_PATCH, eb, B, N, H, W));
+    if (eb == 4 && H >= 128 && W >= 128)
+        m = std::max(m, ws_impl(IMPL_ZTILE, eb, B, N, H, W));
+    return ws_common(eb, B, N, H, W) + m;
+}
+
+// ... and with them: exactly what the call will carve
+static inline size_t ibp_ws_for(int eb, int B, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
+{
+    return ws_common(eb, B, N, H, W) + ws_impl(choose_impl(eb, N, H, W, sh, k, kh, kw, f), eb, B, N, H, W);
 }
 
 template <typename T>
 static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
                const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
-               size_t wsb, hipStream_t st)
+               size_t wsb, hipStream_t st, const char **took)
 {
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
     AxisPlan py, px;
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
+    const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : "mosaic";  // what srx_last_path() reports: the branch taken
     Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
     const int NS = (N + 3) & ~3;                        // slots per near-band pixel
-    T *pad = ar.take<T>((size_t)B * Hp * Wp);
-    T *G = ar.take<T>((size_t)B * Hg * Wg), *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
+    T *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
     T *Mu = ar.take<T>((size_t)B * NB);
     MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = ar.take<double>(B);
     int *ncu = ar.take<int>(NB), *nyx = ar.take<int>((size_t)NB * NS);
-    double *epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
+    T *pad = nullptr, *G = nullptr;
+    double *epart = nullptr;
+    if (impl == IMPL_TILES) {
+        pad = ar.take<T>((size_t)B * Hp * Wp);
+        G = ar.take<T>((size_t)B * Hg * Wg);
+        epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
+    }
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
@@ -1127,14 +1174,12 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     if constexpr (sizeof(T) == 4) {
-        // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp).
-        // Its transposed far-field operands take the places of the planes it does not need (G and the blurred plane).
-        if (!(call_flags() & SRX_FLAG_TILES) && patch::eligible(4, N, H, W, sh, k, kh, kw, f)) {
+        // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp)
+        if (impl == IMPL_PATCH)
             return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
                                   errors, st);
-        }
-        // integer HR shifts on a large frame: the whole iteration in one launch over CU-resident 256 x 256 tiles (srx_ztile.hpp)
-        if (ztile::eligible(4, N, H, W, sh, k, kh, kw, f))
+        // integer HR shifts on a large frame: the whole iteration in one launch over CU-resident 64 x 256 tiles (srx_ztile.hpp)
+        if (impl == IMPL_ZTILE)
             return ztile::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale,
                                   errors, st);
     }

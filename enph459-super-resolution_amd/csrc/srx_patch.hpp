@@ -142,7 +142,19 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
         return false;
     fused::Kernel7<float> kc;
     fused::make_kernel7<float>(k, kh, kw, false, kc);
-    return kc.separable && axis_ok(py, N, f) && axis_ok(px, N, f);
+    if (!(kc.separable && axis_ok(py, N, f) && axis_ok(px, N, f)))
+        return false;
+    // the near band within the kernel's two-pixels-per-thread descriptor lists (iterate() computes the same count)
+    auto span = [&](const mosaic::AxisPlan &pl, int &ex, int &nb) {
+        int nmin = pl.n[0], nmax = pl.n[0];
+        for (int q = 1; q < N; q++)
+            nmin = std::min(nmin, pl.n[q]), nmax = std::max(nmax, pl.n[q]);
+        ex = nmax, nb = -nmin;
+    };
+    int exy, nby, exx, nbx;
+    span(py, exy, nby);
+    span(px, exx, nbx);
+    return (exy + nby) * (PN + exx) + (PN - nby) * (exx + nbx) <= NN_PAD;
 }
 
 // ---- once per call: transposed far-field operands ---------------------------------------------------------------------

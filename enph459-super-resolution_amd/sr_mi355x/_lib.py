@@ -50,6 +50,7 @@ _PLAIN = {
     "srx_backproject_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "srx_saa_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "srx_ibp_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _U]),
+    "srx_ibp_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _HD, _HD, _I, _I, _U]),
 }
 
 

@@ -223,7 +223,7 @@ def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, p
             raise ValueError(f"out must be a contiguous CUDA tensor of dtype {_TORCH_DT[prec]} and shape {(B, H, W)}")
     hr = torch.empty_like(h0) if out is None else out
     errors = torch.empty((B, int(n_iter)), dtype=torch.float64, device=x.device) if want_errors else None
-    wt, wp, wn = _ws(_lib.load().srx_ibp_workspace_bytes(_ELEM[prec], B, N, h, w, H, W, f, flags))
+    wt, wp, wn = _ws(_lib.load().srx_ibp_workspace_bytes_for(_ELEM[prec], B, N, h, w, H, W, f, shp, kp, k.shape[0], k.shape[1], flags))
     _lib.check(_fn("srx_ibp", prec)(_p(x), B, N, h, w, shp, kp, k.shape[0], k.shape[1], _p(h0), H, W, f, int(n_iter),
                                     float(step), _p(hr), _p(errors) if want_errors else None, wp, wn, _stream(), flags),
                "srx_ibp")

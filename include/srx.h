@@ -137,6 +137,10 @@ int srx_saa_f64(const double *lr, int B, int N, int h, int w, const double *shif
  * float64 [B, n_iter] = the reference's `errors` list per item (mean over frames of the mean
  * squared LR residual BEFORE that iteration's update); may be NULL to skip it. */
 size_t srx_ibp_workspace_bytes(int elem_bytes, int B, int N, int h, int w, int H, int W, int factor, unsigned flags);
+/* The same with the call's shift table and PSF at hand: exactly what that call will carve (<= the bound above, which must cover
+ * every implementation the shape admits). */
+size_t srx_ibp_workspace_bytes_for(int elem_bytes, int B, int N, int h, int w, int H, int W, int factor, const double *shifts_yx,
+                                   const double *kernel, int kh, int kw, unsigned flags);
 int srx_ibp_f32(const float *lr, int B, int N, int h, int w, const double *shifts_yx, const double *kernel, int kh,
                 int kw, const float *hr_init, int H, int W, int factor, int n_iter, double step, float *hr_out,
                 double *errors_out, void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);

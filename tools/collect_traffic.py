@@ -11,12 +11,30 @@ its WRITE_SIZE (262 144 KiB) is exact.  So bytes = (2 * FETCH_SIZE + WRITE_SIZE)
 A kernel that runs all IBP iterations in one launch (k_ibp_patch) is divided by the iteration count of the profiled run, so
 that every entry also carries `hbm_bytes_per_iteration` (what bench.py's roofline.traffic sums).
 
-usage: collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <workload tag> <iters of the run> [out.json]
+Every entry is stamped with the profile tag it came from and with the hash of the kernel sources at collection time
+(source_sha16: sha256 over enph459-super-resolution_amd/csrc/*), which bench.py compares with the sources it runs: a traffic figure
+measured on other kernels is reported as stale instead of passing silently.
+
+usage: collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <workload tag> <iters of the run> [out.json] [profile tag]
 """
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha16():
+    """sha256 over the kernel sources (sorted by name): the identity of the code a measurement belongs to."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "enph459-super-resolution_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 PERSISTENT = ("k_ibp_patch",)  # one call = all iterations
@@ -37,7 +55,7 @@ def per_kernel(path, counter):
 def main():
     iters = int(sys.argv[4])
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"iters": iters, "kernels": {}}
+    out = {"iters": iters, "profile_tag": sys.argv[6] if len(sys.argv) > 6 else None, "source_sha16": source_sha16(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue

@@ -12,7 +12,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WL = {"c2": "c2:B=1024:f32", "c3_mono": "c3_mono:B=1:f32"}
+WL = {"c2": "c2:B=1024:f32", "c3_mono": "c3_mono:B=1:f32", "c3_mono_measured": "c3_mono_measured:B=1:f32", "c3_f4": "c3_f4:B=1:f32",
+      "c3_rgb": "c3_rgb:B=1:f32"}
 
 
 def one(pattern):
@@ -38,18 +39,21 @@ def main():
     tag = sys.argv[1]
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     for wl, wtag in WL.items():
+        if not glob.glob(f"{src}/{wl}_stats/*_kernel_stats.csv"):
+            continue  # a workload this round's profile_round.sh did not run
         shutil.copy(one(f"{src}/{wl}_stats/*_kernel_stats.csv"), f"{dst}/{tag}_{wl}_kernel_stats.csv")
         fetch, write = one(f"{src}/{wl}_fetch/*_counter_collection.csv"), one(f"{src}/{wl}_write/*_counter_collection.csv")
         shutil.copy(fetch, f"{dst}/{tag}_{wl}_pmc_fetch_size.csv")
         shutil.copy(write, f"{dst}/{tag}_{wl}_pmc_write_size.csv")
         line = json.loads(open(f"{src}/{wl}_bench.json").read().strip().splitlines()[-1])
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py"), fetch, write, wtag,
-                               str(line["config"]["n_iter"]), f"{dst}/traffic.json"], stdout=subprocess.DEVNULL)
+                               str(line["config"]["n_iter"]), f"{dst}/traffic.json", tag], stdout=subprocess.DEVNULL)
         json.dump(line, open(f"{dst}/{tag}_{wl}_bench.json", "w"))
         # SQ summary: the iteration kernel(s) of this workload, mean per launch
         c = counters(one(f"{src}/{wl}_sq1/*_counter_collection.csv"))
         for k, d in counters(one(f"{src}/{wl}_sq2/*_counter_collection.csv")).items():
             c.setdefault(k, {}).update(d)
+        valu = {}
         with open(f"{dst}/{tag}_{wl}_pmc_sq.txt", "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --pmc <8 counters> (two passes), workload {wtag}, mean per launch; tools/profile_round.sh\n")
             f.write("# VALU busy = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / (GRBM_GUI_ACTIVE / 8 XCDs)   (issue cost: profiles/README.md, microbenchmark)\n")
@@ -62,8 +66,17 @@ def main():
                     f.write(f"    {n:28s} {d[n]:18.1f}\n")
                 if "SQ_INSTS_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
                     cyc = d["GRBM_GUI_ACTIVE"] / 8
+                    valu[k.split("<")[0]] = {"valu_busy": round(d["SQ_INSTS_VALU"] / 1024 * 2 / cyc, 4),
+                                             "wave_cycles_waiting": round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 4),
+                                             "method": "SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / (GRBM_GUI_ACTIVE / 8 XCDs); SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
                     f.write(f"    -> VALU busy {d['SQ_INSTS_VALU'] / 1024 * 2 / cyc:.3f}, wave-cycles waiting {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.3f}, "
                             f"GPU cycles per launch {cyc:.0f}\n")
+        # the VALU view of the same kernels goes beside their traffic (bench.py's roofline.valu)
+        doc = json.load(open(f"{dst}/traffic.json"))
+        for k, v in valu.items():
+            if k in doc["workloads"][wtag]["kernels"] and v["valu_busy"] > doc["workloads"][wtag]["kernels"][k].get("valu_busy", -1):
+                doc["workloads"][wtag]["kernels"][k].update(v)  # (of k_ibp_patch's two instantiations: the one that did the work)
+        json.dump(doc, open(f"{dst}/traffic.json", "w"), indent=1)
     print(open(f"{dst}/traffic.json").read())
 
 

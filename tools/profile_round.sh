@@ -1,7 +1,7 @@
 #!/bin/bash
 # profile_round.sh TAG -- the rocprofv3 evidence of one round, collected on the GPU box in ONE gpurun call:
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r02'
-# For each of the two workloads bench.py reports a roofline for (C2 = k_ibp_patch, C3-mono = k_ibp_ztile):
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03 "c2 c3_mono"'
+# For each workload named (default: every workload bench.py reports a roofline for):
 #   <wl>_stats : rocprofv3 --kernel-trace --stats            (per-kernel durations)
 #   <wl>_fetch : rocprofv3 --kernel-trace --pmc FETCH_SIZE   (separate pass, as MI355X_MICROARCH.md prescribes)
 #   <wl>_write : rocprofv3 --kernel-trace --pmc WRITE_SIZE
@@ -9,7 +9,8 @@
 # Everything lands in gpurun_out/TAG/; tools/profile_collect.py TAG turns it into profiles/TAG_* afterwards (on the dev box).
 # The program after "--" is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
+WLS=${2:-"c2 c3_mono c3_mono_measured c3_f4 c3_rgb"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -18,7 +19,7 @@ export TMPDIR=/tmp
 COMMON="--steps 1 --no-cpu-baseline --no-roofline --no-secondary"
 SQ1="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
 SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
-for wl in c2 c3_mono; do
+for wl in $WLS; do
     echo "== $wl kernel stats"
     # (six calls: the first call after a pause runs the long kernels ~8 % slow, which a two-call average would show)
     timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${wl}_stats" -o run -- python3 "$R/bench.py" --workload $wl --warmup 2 --steps 4 --no-cpu-baseline --no-roofline --no-secondary > "$O/${wl}_stats.log" 2>&1
@@ -35,7 +36,12 @@ for wl in c2 c3_mono; do
 done
 echo "== bench lines"
 cd "$R"
-timeout -k 10 500 python3 bench.py --steps 3 --warmup 1 > "$O/c2_bench.json" 2> "$O/c2_bench.err"
-timeout -k 10 200 python3 bench.py --workload c3_mono --steps 3 --warmup 1 --no-cpu-baseline > "$O/c3_mono_bench.json" 2> "$O/c3_mono_bench.err"
-tail -c 600 "$O/c2_bench.json"
+for wl in $WLS; do
+    if [ "$wl" = c2 ]; then
+        timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > "$O/c2_bench.json" 2> "$O/c2_bench.err"
+    else
+        timeout -k 10 200 python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > "$O/${wl}_bench.json" 2> "$O/${wl}_bench.err"
+    fi
+done
+tail -c 600 "$O/c2_bench.json" || true
 echo PROFILE_ROUND_DONE
