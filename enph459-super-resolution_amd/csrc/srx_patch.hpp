@@ -362,6 +362,50 @@ __device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64]
     }
 }
 
+// ---- the recursion a[i] <- z a[i -+ 1] + a[i] over the 64 samples of a lane, as NSUB independent sub-chains ---------------------------
+// One chain is 64 DEPENDENT fmas, and a dependent fma issues every ~11 cycles (tools/microbench/valu_issue.hip): a wave that runs its
+// chain alone -- the usual case, the waves of a SIMD leave the throughput-bound phases one after the other -- idles 9 of 11 cycles.
+// The recursion is linear, so the identity that joins the BLOCKS also cuts a chain inside a lane: sub-chain k > 0 starts from a zero
+// state, and the true state at its start -- the end value of sub-chain k - 1 -- is added afterwards as z^(i+1) * state over its first
+// FIX = 16 samples (|z|^17 = 2e-10).  Measured on one box (C2, tools/ab_bench.sh): one chain 138.3 us per iteration, two sub-chains
+// 132.8, four (16 steps, then 3 x 16 fix-up fmas whose end values are themselves fixed first) 141.8 -- with four waves per SIMD the
+// chains of several waves already overlap, and the fix-ups are real work.
+#ifndef SRX_CHAIN_NSUB
+#define SRX_CHAIN_NSUB 2
+#endif
+template <bool REV> __device__ __forceinline__ void chain64(float (&a)[64], float st0)
+{
+    constexpr int NSUB = SRX_CHAIN_NSUB, L = 64 / NSUB;
+    static_assert(NSUB == 1 || L >= FIX, "a fix-up may not reach into the next sub-chain's start");
+    const float z = PZ;
+    auto at = [&](int i) -> float & { return a[REV ? 63 - i : i]; };  // position along the direction of the recursion
+    float st[NSUB];
+#pragma unroll
+    for (int k = 0; k < NSUB; k++)
+        st[k] = k == 0 ? st0 : 0.f;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+        for (int k = 0; k < NSUB; k++) {
+            st[k] = fmaf(z, st[k], at(k * L + i));
+            at(k * L + i) = st[k];
+        }
+    }
+    if (NSUB > 1) {
+        float e[NSUB];  // true end values of the sub-chains
+        e[0] = st[0];
+#pragma unroll
+        for (int k = 1; k < NSUB; k++)
+            e[k] = L == FIX ? fmaf(ZP.v[FIX - 1], e[k - 1], st[k]) : st[k];  // (longer sub-chains: the end is out of the fix-up's reach)
+#pragma unroll
+        for (int k = 1; k < NSUB; k++) {
+#pragma unroll
+            for (int i = 0; i < FIX; i++)
+                at(k * L + i) = fmaf(ZP.v[i], e[k - 1], at(k * L + i));
+        }
+    }
+}
+
 // ---- forward chain of one block, in place ------------------------------------------------------------------------------
 // a[] in: kq-scaled blurred samples b' of this block.  out: Y[rho], rho = the block's own 64 indices;
 // Y[rho] = sum_a wf[a] c[rho - 2 + a], c = P(pad12(b)).  yex (first block): Y[-1].
@@ -372,12 +416,7 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
 {
     const float z = PZ;
     const float bfirst = a[0], blast = a[63];
-    float st = first ? bfirst * K2 : 0.f;  // inside the constant pad the causal state is the steady state
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        st = fmaf(z, st, a[i]);
-        a[i] = st;
-    }
+    chain64<false>(a, first ? bfirst * K2 : 0.f);  // inside the constant pad the causal state is the steady state
     Rown[sa + lane] = a[63];
     __syncthreads();
     if (!first) {
@@ -388,12 +427,7 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
     }
     // coefficient of the first sample below the line: 12 constant pad samples, then SciPy's reflect end (z^24 away)
     const float cb = last ? fmaf(a[63] - blast * K2, K3, blast * K1) : 0.f;
-    st = cb;
-#pragma unroll
-    for (int i = 63; i >= 0; i--) {
-        st = fmaf(z, st, a[i]);
-        a[i] = st;
-    }
+    chain64<true>(a, cb);
     float cm1 = 0.f, cm2 = 0.f;  // c[-1], c[-2] relative to the block
     if (first) {                 // coefficients inside the top pad: c[i] = z c[i+1] + qs
         const float qs = bfirst * K2;
@@ -444,14 +478,15 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
         st = fmaf(z, st, (w0 + w1 + w2) * gtop + w3 * a[0]);
         st = fmaf(z, st, (w0 + w1) * gtop + w2 * a[0] + w3 * a[1]);
     }
+    // the FIR in place (independent fmas), then the recursion on its output
     float gprev = gm1;
 #pragma unroll
     for (int t = 0; t < 64; t++) {
         const float g0 = a[t], g1 = t < 63 ? a[t + 1] : gp1, g2 = t < 62 ? a[t + 2] : (t == 62 ? gp1 : gp2);
-        st = fmaf(z, st, w0 * gprev + w1 * g0 + w2 * g1 + w3 * g2);
+        a[t] = w0 * gprev + w1 * g0 + w2 * g1 + w3 * g2;
         gprev = g0;
-        a[t] = st;
     }
+    chain64<false>(a, st);
     SRX_PSTAMP(16);
     Rown[s1 + lane] = a[63];
     __syncthreads();
@@ -463,12 +498,7 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
             a[i] = fmaf(ZP.v[i], carry, a[i]);
     }
     const float cb = last ? fmaf(z, a[63], vn) * K4 : 0.f;
-    st = cb;
-#pragma unroll
-    for (int i = 63; i >= 0; i--) {
-        st = fmaf(z, st, a[i]);
-        a[i] = st;
-    }
+    chain64<true>(a, cb);
     Rown[s6 + lane] = a[0];
     Rown[s6 + 64 + lane] = a[1];
     Rown[s6 + 128 + lane] = a[2];
