@@ -68,6 +68,8 @@ def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
         "k_bwd_mosaic": B * (H + 27) * (W + 27) * eb + 2 * hw,   # read G + hr, write hr
         # one launch = all n_iter iterations of a patch: SURVEY 8d's per-iteration bytes (read + write hr, read the LR samples)
         "k_ibp_patch": n_iter * (2 * hw + lrn),
+        "k_ibp_ztile": 2 * hw + lrn,            # one launch = one iteration
+        "k_ibp_dtile": 2 * hw + lrn,
     }.get(name)
 
 
@@ -180,6 +182,8 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
                                                                   "avg_us": round(tot.value / cnt.value * 1e3, 2)}
     lib.srx_profile_enable(0)
     per_iter = {k: v["avg_us"] for k, v in kernels.items() if v["launches"] == n_iter and k != "k_ibp_patch"}
+    if "k_ibp_dtile" in kernels:  # a pair of launches per iteration (byte / float form of the mosaic: an item is iterated by exactly one)
+        per_iter["k_ibp_dtile"] = kernels["k_ibp_dtile"]["total_ms"] * 1e3 / n_iter
     if "k_ibp_patch" in kernels:  # all iterations of a patch in one launch
         per_iter["k_ibp_patch"] = kernels["k_ibp_patch"]["total_ms"] * 1e3 / n_iter
     out["kernels"] = kernels
@@ -193,7 +197,8 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
                             "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         # k_ibp_patch runs as a pair of launches (byte / float form of the mosaic; a patch is iterated by exactly one of them, the
         # other's blocks leave at once): "one launch" of the roofline is the pair
-        launch_us = round(kernels[dom]["total_ms"] * 1e3, 2) if dom == "k_ibp_patch" else kernels[dom]["avg_us"]
+        launch_us = (round(kernels[dom]["total_ms"] * 1e3, 2) if dom == "k_ibp_patch" else round(per_iter[dom], 2) if dom == "k_ibp_dtile"
+                     else kernels[dom]["avg_us"])
         out["dominant"] = {"kernel": dom, "avg_launch_us": launch_us, "algorithmic_bytes_per_launch": nbytes,
                            "achieved": round(nbytes / (launch_us * 1e-6) / 1e9, 1) if nbytes else None,
                            "frac": round(nbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if nbytes else None}

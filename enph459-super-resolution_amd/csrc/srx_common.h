@@ -86,6 +86,7 @@ enum KernelId {
     KID_PREFILTER_TILE,
     KID_IBP_PATCH,
     KID_IBP_ZTILE,
+    KID_IBP_DTILE,
     KID_COUNT
 };
 

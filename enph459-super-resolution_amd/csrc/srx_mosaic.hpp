@@ -42,6 +42,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
                    double scale, double *errors, hipStream_t st);
 }  // namespace ztile
+namespace dtile {  // srx_dtile.hpp: a common fraction > 0 on large frames, overlapping register-resident windows, one launch per iteration
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline size_t tabs_bytes(int B, int N, int H, int W);
+static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st);
+}  // namespace dtile
 namespace patch {
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
@@ -1051,14 +1059,16 @@ __global__ void __launch_bounds__(256)
 // one of them uses (M, C, Mu, the tap tables, the near-band lists):
 //   tiles : the blurred plane, G, per-tile MSE partials      patch : srx_patch.hpp's operand planes and tables
 //   ztile : srx_ztile.hpp's padded state / operand planes and tables
-enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2 };
+enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3 };
 
 static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
-    if (eb == 4 && !(call_flags() & SRX_FLAG_TILES) && patch::eligible(eb, N, H, W, sh, k, kh, kw, f))
+    if (eb == 4 && !(call_flags() & (SRX_FLAG_TILES | SRX_FLAG_DIAG_WIDE_WINDOWS)) && patch::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_PATCH;
     if (ztile::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_ZTILE;
+    if (dtile::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_DTILE;
     return IMPL_TILES;
 }
 
@@ -1079,6 +1089,8 @@ static inline size_t ws_impl(Impl im, int eb, int B, int N, int H, int W)
         return patch::tabs_bytes(B, N);
     if (im == IMPL_ZTILE)
         return ztile::tabs_bytes(B, N, H, W);
+    if (im == IMPL_DTILE)
+        return dtile::tabs_bytes(B, N, H, W);
     return align_up((size_t)B * Hp * Wp * eb) + align_up((size_t)B * Hg * Wg * eb) +
            align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
@@ -1091,6 +1103,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
         m = std::max(m, ws_impl(IMPL_PATCH, eb, B, N, H, W));
     if (eb == 4 && H >= 128 && W >= 128)
         m = std::max(m, ws_impl(IMPL_ZTILE, eb, B, N, H, W));
+    if (eb == 4 && H >= 256 && W >= 256 && H % 4 == 0 && W % 16 == 0)
+        m = std::max(m, ws_impl(IMPL_DTILE, eb, B, N, H, W));
     return ws_common(eb, B, N, H, W) + m;
 }
 
@@ -1110,7 +1124,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
     const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
-    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : "mosaic";  // what srx_last_path() reports: the branch taken
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : "mosaic";  // what srx_last_path() reports: the branch taken
     Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
     const int NS = (N + 3) & ~3;                        // slots per near-band pixel
@@ -1179,6 +1193,9 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
             return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
                                   errors, st);
         // integer HR shifts on a large frame: the whole iteration in one launch over CU-resident 64 x 256 tiles (srx_ztile.hpp)
+        if (impl == IMPL_DTILE)
+            return dtile::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors,
+                                  st);
         if (impl == IMPL_ZTILE)
             return ztile::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale,
                                   errors, st);

@@ -63,6 +63,7 @@ typedef enum {
 #define SRX_FLAG_DIAG_NO_ZERO_FUSE 0x100u      /* delta = 0: separate blur and index-map kernels */
 #define SRX_FLAG_DIAG_NO_SEPARABLE 0x200u      /* 7x7 form of a rank-1 PSF */
 #define SRX_FLAG_DIAG_NO_PREFILTER_TILE 0x400u /* line prefilter kernels for float planes */
+#define SRX_FLAG_DIAG_WIDE_WINDOWS 0x1000u     /* delta != 0 frames: 256-column windows whatever the plan's cost model says */
 #define SRX_FLAG_DIAG_V1 0x800u                /* per-frame fused path with stand-alone prefilter passes (8 launches / iteration) */
 
 int srx_version(void);
