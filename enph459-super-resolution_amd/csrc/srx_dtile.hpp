@@ -14,8 +14,8 @@
 //     its own: four rows interleaved ([H / 4][W][4]), one 16-byte access per lane and four rows -- a CU issues one vector memory
 //     instruction per ~9 cycles whatever its width (srx_patch.hpp), and a window loads, re-reads and stores 64 rows per wave.
 //   * Window shape: 4 x 4 waves (256 x 256, 192 x 192 owned) recompute the least; 4 x 3 waves (256 x 192) leave fewer idle compute
-//     units when ONE frame is all there is (3072 x 4096: 336 windows of 16 waves = 1.31 rounds of 256 CUs, or 512 of 12 waves = 2.00).
-//     plan() picks by modelled time.
+//     units when ONE frame is all there is (3072 x 4096: 336 windows of 16 waves = 1.31 rounds of 256 CUs at 55 us per round, or 512 of
+//     12 waves = 2.00 rounds at 37 us).  plan() picks by modelled time of one frame.
 //   * Near band, count masks, byte mosaic: k_ibp_patch's, per window (only windows on the top / left image edge hold near-band
 //     pixels; the tables are built per such window).
 #pragma once
@@ -120,7 +120,7 @@ struct Plan {
     AxisTiles ty, tx;
 };
 
-static inline bool plan(int H, int W, int B, Plan &pl)
+static inline bool plan(int H, int W, Plan &pl)
 {
     Plan best;
     double bt = 1e30;
@@ -129,11 +129,13 @@ static inline bool plan(int H, int W, int B, Plan &pl)
         p.nsx = nsx;
         if (!plan_axis_tiles(H, RY, ALIGN_Y, p.ty) || !plan_axis_tiles(W, 64 * nsx, ALIGN_X, p.tx))
             continue;
-        // one window per compute unit at a time; a 12-wave window runs ~0.8 of a 16-wave one (fewer waves share a SIMD)
+        // One window per compute unit at a time, modelled for ONE frame (a batch must give every item the result it would get alone, bit
+        // for bit, so the plan may not depend on the batch).  Measured on 3072 x 4096 (round 3): a round of 12-wave windows 37 us, of
+        // 16-wave windows 55 us; eight frames 592 against 574 us per iteration -- what the narrow shape loses on a batch is 3 %.
         const long tiles = (long)p.ty.n * p.tx.n;
         if (tiles > 1024)
             continue;
-        const double t = (double)((tiles * B + 255) / 256) * (nsx == 4 ? 1.0 : 0.8);
+        const double t = (double)((tiles + 255) / 256) * (nsx == 4 ? 1.0 : 0.68);
         if (t < bt)
             bt = t, best = p;
     }
@@ -163,7 +165,7 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
     if (!(kc.separable && patch::axis_ok(py, N, f) && patch::axis_ok(px, N, f)))
         return false;
     Plan pl;
-    if (!plan(H, W, 1, pl))
+    if (!plan(H, W, pl))
         return false;
     int exy, nby, exx, nbx;
     axis_span(py, N, exy, nby);
@@ -342,18 +344,15 @@ __global__ void __launch_bounds__(NTHR)
 // operand planes' pitch, and that the MSE sum and the store are restricted to the pixels this window owns.
 // =========================================================================================================================
 template <bool C01, bool M8, int NSX>
-__global__ void __launch_bounds__(256 * NSX)
-    k_ibp_dtile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, DTabs tb, DArgs da, double *__restrict__ epart,
-                const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
+__device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__ hr_src, float *__restrict__ hr_dst, const DTabs &tb, const DArgs &da,
+                                           double *__restrict__ epart, const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale,
+                                           double *__restrict__ err_prev, int err_stride)
 {
     using L = Lds<NSX>;
     constexpr int NW = L::NW, NTHR = 64 * NW, NPT = (NN_PAD + NTHR - 1) / NTHR;  // near-band pixels per thread
-    __shared__ float lds[L::WORDS];
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), s = wave / NSX, u = wave - s * NSX;
     const int b = blockIdx.y;
-    if ((__builtin_amdgcn_readfirstlane(tb.m8[b]) != 0) != M8)
-        return;
     constexpr int m8 = M8 ? 1 : 0;
     TileD td;
     {
@@ -701,6 +700,23 @@ __global__ void __launch_bounds__(256 * NSX)
 #undef SRX_DT_LOCALS
 }
 
+// The byte form of the mosaic (items whose samples are 8-bit integers: the sensor's format) and the float form are two instantiations
+// of the body behind one workgroup-uniform branch at the very top: ONE launch per iteration.  (k_ibp_patch launches the two forms one
+// after the other and lets the blocks of the wrong one leave; per iteration that is a second launch of a full grid of workgroups --
+// 4.8 us + a gap on a 74 us kernel, C3-f4.  As a branch INSIDE the iteration the two G steps cost 40 spilled registers, srx_patch.hpp;
+// two whole bodies do not share a live range.)
+template <bool C01, int NSX>
+__global__ void __launch_bounds__(256 * NSX)
+    k_ibp_dtile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, DTabs tb, DArgs da, double *__restrict__ epart,
+                const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
+{
+    __shared__ float lds[Lds<NSX>::WORDS];
+    if (__builtin_amdgcn_readfirstlane(tb.m8[blockIdx.y]) != 0)
+        dtile_body<C01, true, NSX>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
+    else
+        dtile_body<C01, false, NSX>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 static inline size_t tabs_bytes(int B, int N, int H, int W)
 {
@@ -715,12 +731,13 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
 struct FrameN {
     int n[SRX_MAX_FRAMES];
 };
+// grid ceil(max(tiles, 64 * (ty.n + tx.n) * 4) / 256): a thread per window, and a thread per mask BIT (a ballot assembles the word)
 __global__ void __launch_bounds__(256)
     k_dtile_setup(AxisTiles ty, AxisTiles tx, FrameN ny, FrameN nx, int N, int f, int H, int W, int nsx, TileD *__restrict__ tiles,
                   unsigned long long *__restrict__ rowm, unsigned long long *__restrict__ colm)
 {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < ty.n * tx.n; i += 256) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    for (int i = tid; i < ty.n * tx.n; i += gridDim.x * 256) {
         const int y = i / tx.n, x = i - y * tx.n;
         TileD t;
         t.oy = ty.o[y], t.ox = tx.o[x];
@@ -729,31 +746,31 @@ __global__ void __launch_bounds__(256)
         t.ntab = y == 0 ? x : (x == 0 ? tx.n + y - 1 : -1);
         tiles[i] = t;
     }
-    // C[gy, gx] = ry[gy] rx[gx] of a full phase grid (srx_patch.hpp, c01_masks), on the windows' own rows / columns
-    for (int i = tid; i < (ty.n + tx.n) * 4; i += 256) {
-        const bool isy = i < ty.n * 4;
-        const int q = isy ? i : i - ty.n * 4, t = q >> 2, w = q & 3, L = isy ? H : W, nblk = isy ? 4 : nsx;
-        const int o = isy ? ty.o[t] : tx.o[t];
-        unsigned long long m = 0ull;
-        for (int e = 0; e < 64 && w < nblk; e++) {
-            const int g = o + 64 * w + e;
-            for (int k = 0; k < N; k++) {
+    // C[gy, gx] = ry[gy] rx[gx] of a full phase grid (srx_patch.hpp, c01_masks), on the windows' own rows / columns: wave i / 64 owns
+    // mask word i / 64, lane = bit
+    {
+        const int q0 = tid >> 6, e = tid & 63;
+        if (q0 < (ty.n + tx.n) * 4) {
+            const bool isy = q0 < ty.n * 4;
+            const int q = isy ? q0 : q0 - ty.n * 4, t = q >> 2, w = q & 3, L = isy ? H : W, nblk = isy ? 4 : nsx;
+            const int g = (isy ? ty.o[t] : tx.o[t]) + 64 * w + e;
+            bool on = false;
+            for (int k = 0; k < N && w < nblk; k++) {
                 const int uu = g + (isy ? ny.n[k] : nx.n[k]);
-                if (uu >= 0 && uu <= L - 1 && uu % f == 0)
-                    m |= 1ull << e;
+                on = on || (uu >= 0 && uu <= L - 1 && uu % f == 0);
             }
+            const unsigned long long m = __ballot(on);
+            if (e == 0)
+                (isy ? rowm : colm)[q] = m;
         }
-        (isy ? rowm : colm)[q] = m;
     }
 }
 
 template <int NSX, bool C01>
-static int launch_pair(dim3 grid, hipStream_t st, const float *src, float *dst, const DTabs &tb, const DArgs &da, double *ep, const double *eprev,
+static int launch_iter(dim3 grid, hipStream_t st, const float *src, float *dst, const DTabs &tb, const DArgs &da, double *ep, const double *eprev,
                        const double *Vtot, double scale, double *err_prev, int stride)
 {
-    // the byte and the float form of the mosaic: every item is iterated by exactly one (k_ibp_patch does the same)
-    SRX_LAUNCH(KID_IBP_DTILE, (k_ibp_dtile<C01, true, NSX>), grid, dim3(256 * NSX), 0, st, src, dst, tb, da, ep, eprev, Vtot, scale, err_prev, stride);
-    SRX_LAUNCH(KID_IBP_DTILE, (k_ibp_dtile<C01, false, NSX>), grid, dim3(256 * NSX), 0, st, src, dst, tb, da, ep, eprev, Vtot, scale, err_prev, stride);
+    SRX_LAUNCH(KID_IBP_DTILE, (k_ibp_dtile<C01, NSX>), grid, dim3(256 * NSX), 0, st, src, dst, tb, da, ep, eprev, Vtot, scale, err_prev, stride);
     return SRX_OK;
 }
 
@@ -763,7 +780,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
                    double scale, double *errors, hipStream_t st)
 {
     Plan pl;
-    if (!plan(H, W, B, pl))
+    if (!plan(H, W, pl))
         return SRX_E_UNSUPPORTED;
     const int ntiles = pl.ty.n * pl.tx.n, RX = 64 * pl.nsx, ngrp = NS / 4, ntabs = pl.tx.n + pl.ty.n - 1;
     const size_t plane = (size_t)H * W;
@@ -792,7 +809,8 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     FrameN fy, fx;
     for (int q = 0; q < SRX_MAX_FRAMES; q++)
         fy.n[q] = q < N ? py.n[q] : 0, fx.n[q] = q < N ? px.n[q] : 0;
-    hipLaunchKernelGGL(k_dtile_setup, dim3(1), dim3(256), 0, st, pl.ty, pl.tx, fy, fx, N, f, H, W, pl.nsx, tiles, rowm, colm);
+    hipLaunchKernelGGL(k_dtile_setup, dim3(cdiv(std::max(ntiles, 64 * (pl.ty.n + pl.tx.n) * 4), 256)), dim3(256), 0, st, pl.ty, pl.tx, fy, fx, N, f, H, W,
+                       pl.nsx, tiles, rowm, colm);
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(patch::k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
@@ -817,11 +835,11 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         double *eo = errors ? errors + it - 1 : nullptr;
         int rc;
         if (pl.nsx == 4)
-            rc = da.c01 ? launch_pair<4, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
-                        : launch_pair<4, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
+            rc = da.c01 ? launch_iter<4, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
+                        : launch_iter<4, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
         else
-            rc = da.c01 ? launch_pair<3, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
-                        : launch_pair<3, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
+            rc = da.c01 ? launch_iter<3, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
+                        : launch_iter<3, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
         SRX_TRY(rc);
     }
     if (errors) {

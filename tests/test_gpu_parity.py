@@ -352,6 +352,15 @@ def test_frame_kernel_is_deterministic():
         outs = [S.ibp_batched(lr, shifts, psf, init, f, 2, 0.5)[0].clone() for _ in range(30)]
         assert S.last_path() == "ztile"
         assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # the delta != 0 frame kernel, both window shapes (round 3: the 128-bit stores behind which a vector instruction overwrote the data
+    # registers -- tools/microbench/store_data_war.hip -- deviated in 12 of 12 calls of the 4 x 4 shape)
+    f4, sh16 = 4, synth.phase_shifts(4)
+    lr4 = torch.from_numpy(np.rint(rng.uniform(0, 255, (1, 16, 80, 100)))).float().cuda()
+    init4 = torch.from_numpy(rng.uniform(0, 255, (1, 320, 400))).float().cuda()
+    for fl in (S.FLAG_AUTO, S.FLAG_DIAG_WIDE_WINDOWS):
+        outs = [S.ibp_batched(lr4, sh16, synth.gaussian_psf(), init4, f4, 2, 0.5, flags=fl)[0].clone() for _ in range(12)]
+        assert S.last_path() == "dtile"
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
     # and the patch kernel (the same in-wave transposes)
     f, shifts, psf = 4, synth.phase_shifts(4), synth.gaussian_psf()
     lr = torch.from_numpy(np.rint(rng.uniform(0, 255, (64, 16, 64, 64)))).float().cuda()
@@ -643,6 +652,119 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert S.last_path() == "mosaic"
     S.ibp_batched(lr_d[:1].double(), shifts, psf, saa_d[:1].double(), f, 2, 0.5, precision="f64")
     assert S.last_path() == "mosaic"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k_ibp_dtile: frames with a common sub-pixel fraction > 0 on overlapping register-resident windows (srx_dtile.hpp)
+# ---------------------------------------------------------------------------------------------------------
+_PH4 = synth.phase_shifts(4)
+DTILE_CFGS = {
+    # name: (factor, shifts, (h, w) LR, flags, integer frames)
+    "x4_ph16_narrow": (4, _PH4, (80, 100), 0, True),                      # 2 x 4 windows of 4 x 3 waves, byte mosaic, 0/1 count masks
+    "x4_ph16_wide": (4, _PH4, (80, 100), "wide", True),                   # 2 x 2 windows of 4 x 4 waves
+    "x4_ph16_float": (4, _PH4, (80, 100), "wide", False),                 # fractional samples: the float mosaic
+    "x4_ph16_3x3win": (4, _PH4, (160, 176), 0, True),                     # interior windows (no image edge on any side)
+    "x2_ph4": (2, synth.phase_shifts(2), (150, 232), 0, True),            # n in {-1, 0}: nothing above / left of the image
+    "x4_n01": (4, [s for s in _PH4 if s[0] > 0 and s[1] > 0], (80, 100), 0, True),       # n in {0, 1}: samples above the image, no near band inside
+    "x4_sub12": (4, [s for s in _PH4 if s[0] > -0.3], (80, 100), "wide", True),           # 3 x 4 product grid
+    "x4_lattice": (4, [_PH4[0], _PH4[5], _PH4[6], _PH4[6], _PH4[15]], (64, 112), 0, False),  # two frames on one phase: the count plane
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(DTILE_CFGS))
+def test_frame_fraction_kernel_vs_oracle(cfg):
+    """The one-launch delta != 0 frame kernel against the oracle after 1, 2 and 6 iterations (state and MSE trace), against the
+    tile kernels it replaces, in place, and as a batch."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, (h, w), fl, integer = DTILE_CFGS[cfg]
+    flags = S.FLAG_DIAG_WIDE_WINDOWS if fl == "wide" else S.FLAG_AUTO
+    psf = synth.gaussian_psf()
+    O.set_threads(16)
+    try:
+        lrs, saas = [], []
+        for i in range(2):
+            truth = synth.truth_image(h * f, w * f, seed=500 + i)
+            lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=600 + i)
+            lr = lr if integer else lr * 0.75 + 0.3
+            lrs.append(lr), saas.append(O.shift_and_add(list(lr), shifts, f))
+        lr, saa = np.stack(lrs), np.stack(saas)
+        for n in (1, 2, 6):
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5, flags=flags)
+            assert S.last_path() == "dtile"
+            for i in range(2 if n == 6 else 1):
+                hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
+                close(hr[i].cpu().numpy(), hr_o, IBP_TOL["f32"])
+                np.testing.assert_allclose(errs[i].cpu().numpy(), err_o, rtol=ERR_RTOL["f32"])
+    finally:
+        O.set_threads(1)
+    hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "mosaic"
+    assert float((hr - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    buf = torch.from_numpy(saa).cuda().float()
+    hr2, errs2 = S.ibp_batched(lr, shifts, psf, buf, f, 6, 0.5, flags=flags, out=buf)
+    assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
+    one, e1 = S.ibp_batched(lr[1:2], shifts, psf, saa[1:2], f, 6, 0.5, flags=flags)
+    assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
+
+
+def test_frame_fraction_kernel_80_iterations():
+    """80 iterations of the x4 / 16-phase workload on a frame of several windows, against the oracle (the north-star tolerances)."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, psf, (h, w) = 4, _PH4, synth.gaussian_psf(), (80, 100)
+    O.set_threads(16)
+    try:
+        truth = synth.truth_image(h * f, w * f, seed=71)
+        lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=72)
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 80, 0.5)
+    finally:
+        O.set_threads(1)
+    saa = S.shift_and_add(list(lr), shifts, f)
+    close(saa, saa_o, PRIM_TOL["f32"])
+    hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 80, 0.5, verbose=False)
+    assert S.last_path() == "dtile"
+    close(hr, hr_o, IBP_TOL["f32"])
+    np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL["f32"])
+    assert synth.psnr(hr, hr_o) > 90.0 and abs(synth.psnr(hr, truth) - synth.psnr(hr_o, truth)) < 0.01
+    u8_close(hr, hr_o)
+
+
+def test_full_size_x4_frame_paths_agree():
+    """SURVEY 8d's C3-f4 at full size (768 x 1024 -> 3072 x 4096, all 16 phases): the window kernel and the tile kernels agree, noise-free
+    frames of x keep x, repeated calls are bit-identical, and a batch of two equals its items."""
+    S.set_precision("f32")
+    f, shifts, psf = 4, _PH4, synth.gaussian_psf()
+    x = torch.from_numpy(synth.truth_image(384, 512, seed=25)).cuda().float().repeat(8, 8)[None].contiguous()
+    lr = torch.stack([S.forward_model_batched(x, psf, s, f) for s in shifts], dim=1).contiguous()
+    assert lr.shape == (1, 16, 768, 1024)
+    hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
+    assert S.last_path() == "dtile"
+    assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(8)
+    lrn = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255)
+    saa = S.shift_and_add_batched(lrn, shifts, f)
+    hr_d, e_d = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5)
+    assert S.last_path() == "dtile"
+    hr_t, e_t = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "mosaic"
+    assert float((hr_d - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(e_d.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    assert float(e_d[0, -1]) < float(e_d[0, 0])
+    for _ in range(3):
+        hr_r, e_r = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5)
+        assert torch.equal(hr_r, hr_d) and torch.equal(e_r, e_d)
+    two_lr, two_saa = torch.cat([lrn, torch.flip(lrn, dims=(2,))]), None
+    two_saa = S.shift_and_add_batched(two_lr, shifts, f)
+    hr2, e2 = S.ibp_batched(two_lr, shifts, psf, two_saa, f, 6, 0.5)
+    assert torch.equal(hr2[0], hr_d[0]) and torch.equal(e2[0], e_d[0])  # (the window plan does not depend on the batch)
+    hr_w, e_w = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_DIAG_WIDE_WINDOWS)
+    assert float((hr_w - hr_d).abs().max()) < 5e-4  # the two window shapes agree to the warm-up truncation
+    hr2w, e2w = S.ibp_batched(two_lr, shifts, psf, two_saa, f, 6, 0.5, flags=S.FLAG_DIAG_WIDE_WINDOWS)
+    assert torch.equal(hr2w[0], hr_w[0]) and torch.equal(e2w[0], e_w[0])
 
 
 # ---------------------------------------------------------------------------------------------------------
