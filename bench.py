@@ -357,7 +357,8 @@ def main():
     legs = None
     if rank == 0 and world == 1 and not args.no_roofline and not args.no_secondary and args.workload == "c2":
         legs = {}
-        for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c3_mono", "c3_mono", "f32", None), ("c3_rgb", "c3_rgb", "f32", None),
+        for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c3_mono", "c3_mono", "f32", None), ("c3_mono_f64", "c3_mono", "f64", None),
+                                      ("c3_rgb", "c3_rgb", "f32", None),
                                       ("c3_f4", "c3_f4", "f32", None), ("c3_mono_x8", "c3_mono", "f32", 8),
                                       ("c3_mono_measured", "c3_mono_measured", "f32", None), ("c3_rgb_x8", "c3_rgb", "f32", 8)):
             lw = workload(synth, wname, lb if lb else (args.batch if wname == "c2" and args.batch else None), args.iters if wname == "c2" else None)

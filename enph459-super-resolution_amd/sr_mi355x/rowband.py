@@ -6,9 +6,10 @@ The reference's IBP loop (mono_cal_target/run_sr.py:190-209) updates every HR pi
 So rank r, which OWNS the HR rows [a_r, b_r) (cut on the LR lattice), iterates on the sub-image [a_r - halo, b_r + halo) as if it were
 a whole image; what it computes on its own rows equals the one-process result as long as the halo covers the iteration's reach
     D = 2 * (3 + 2 + ceil(max |f * dy|) + R),   R = 24 rows (float64: |z|^24 = 2e-14) or 14 (float32: 1e-8)
-and after every iteration (or every m iterations with a halo of m * D rows) the halo rows are replaced by the neighbours' own rows:
-two point-to-point messages per neighbour and round (RCCL send/recv over xGMI on the GPUs; gloo in the CPU test), no collective on
-the data path.  The MSE trace (run_sr.py:202,206) is a sum over LR rows: each rank adds up its own rows' residuals, and ONE all-reduce
+and after every m iterations (halo of m * D rows; `iters_per_exchange`, 2 by default in run_sr: half the messages, one library call
+per round) the halo rows are replaced by the neighbours' own rows: two point-to-point messages per neighbour and round -- device
+tensors over RCCL send / recv (xGMI) on a side stream on the GPUs, host copies over gloo in the CPU test -- no collective on the data
+path.  Only the rank's own band + halo of the LR frames and of the initial image is uploaded.  The MSE trace (run_sr.py:202,206) is a sum over LR rows: each rank adds up its own rows' residuals, and ONE all-reduce
 of the [n_iter] vector at the end of the call completes it -- the trace never feeds back into the iteration.
 
 The compute behind the cut is an "engine" (duck-typed): `GpuEngine` below drives libsrx; the CPU test plugs in the oracle.  Nothing
@@ -69,13 +70,19 @@ class GpuEngine:
         return hr[0]
 
     def sse_rows(self, lr_sub, hr_sub, lo, hi):
-        """sum over frames of sum((lr_k - forward_model(hr, k))^2) over the LR rows [lo, hi) of the sub-image, float64."""
-        tot = 0.0
+        """sum over frames of sum((lr_k - forward_model(hr, k))^2) over the LR rows [lo, hi) of the sub-image: a float64 DEVICE scalar
+        (no host sync: the caller stacks the iterations' scalars and reads them once, after the last iteration)."""
+        tot = self.torch.zeros((), dtype=self.torch.float64, device="cuda")
         for k, s in enumerate(self.shifts):
             sim = self.api.forward_model_batched(hr_sub[None], self.kernel, s, self.f, precision=self.prec)[0]
             e = (lr_sub[k, lo:hi] - sim[lo:hi]).double()
-            tot += float((e * e).sum().item())
+            tot += (e * e).sum()
         return tot
+
+    def halo_stream(self):
+        """A side stream for the halo traffic: the rows a neighbour needs leave while this rank is still iterating (ibp_row_bands
+        sends them as soon as the round that produced them is queued, and waits for the neighbours' rows only before the next round)."""
+        return self.torch.cuda.Stream()
 
     def rows_to_wire(self, t, on_device):  # a block of rows as a contiguous tensor the process group can send
         t = t.contiguous()
@@ -89,6 +96,14 @@ class GpuEngine:
 
     def to_host(self, t):
         return t.double().cpu().numpy()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def _group_info(group):
@@ -123,29 +138,37 @@ def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5,
     hr_sub = eng.load(hr_init[A:B])
     on_dev = backend is not None and "nccl" in backend  # CUDA tensors travel over RCCL; a gloo-only group gets host copies
     up, dn = (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
-    sse = np.zeros(n_iter, dtype=np.float64)
+    sse_parts = []  # one scalar per iteration: device scalars for the GPU engine (read once, at the end), floats for a host engine
+    side = eng.halo_stream() if (on_dev and hasattr(eng, "halo_stream")) else None
 
     def exchange():
-        # my first / last `halo_rows` own rows go to the neighbour whose halo they are; its own rows fill my halo
+        # my first / last `halo_rows` own rows go to the neighbour whose halo they are; its own rows fill my halo.  On the GPUs the
+        # rows stay device tensors (RCCL send / recv over xGMI) and travel on a side stream behind the round that produced them
         ops, recvs = [], []
-        for nb, own_lo, halo_lo in ((up, a - A, a - A - halo_rows), (dn, b - A - halo_rows, b - A)):
-            if nb is None:
-                continue
-            send = eng.rows_to_wire(hr_sub[own_lo:own_lo + halo_rows], on_dev)
-            recv = eng.empty_wire(halo_rows, W, on_dev)
-            ops += [dist.P2POp(dist.isend, send, nb, group), dist.P2POp(dist.irecv, recv, nb, group)]
-            recvs.append((halo_lo, recv))
-        for req in (dist.batch_isend_irecv(ops) if ops else []):
-            req.wait()
-        for halo_lo, recv in recvs:
-            eng.rows_from_wire(hr_sub[halo_lo:halo_lo + halo_rows], recv)
+        if side is not None:
+            side.wait_stream(eng.torch.cuda.current_stream())
+        ctx = eng.torch.cuda.stream(side) if side is not None else _null()
+        with ctx:
+            for nb, own_lo, halo_lo in ((up, a - A, a - A - halo_rows), (dn, b - A - halo_rows, b - A)):
+                if nb is None:
+                    continue
+                send = eng.rows_to_wire(hr_sub[own_lo:own_lo + halo_rows], on_dev)
+                recv = eng.empty_wire(halo_rows, W, on_dev)
+                ops += [dist.P2POp(dist.isend, send, nb, group), dist.P2POp(dist.irecv, recv, nb, group)]
+                recvs.append((halo_lo, recv))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            for halo_lo, recv in recvs:
+                eng.rows_from_wire(hr_sub[halo_lo:halo_lo + halo_rows], recv)
+        if side is not None:
+            eng.torch.cuda.current_stream().wait_stream(side)  # the next round reads the halo rows
 
     it = 0
     while it < n_iter:
         n = min(m, n_iter - it)
         if want_errors:
             for j in range(n):
-                sse[it + j] = eng.sse_rows(lr_sub, hr_sub, (a - A) // f, (b - A) // f)
+                sse_parts.append(eng.sse_rows(lr_sub, hr_sub, (a - A) // f, (b - A) // f))
                 hr_sub = eng.iterate(lr_sub, hr_sub, 1)
         else:
             hr_sub = eng.iterate(lr_sub, hr_sub, n)
@@ -154,6 +177,11 @@ def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5,
             exchange()
     errors = None
     if want_errors:
+        if sse_parts and hasattr(sse_parts[0], "device"):  # device scalars: ONE transfer for the whole trace
+            import torch
+            sse = torch.stack(sse_parts).cpu().numpy()
+        else:
+            sse = np.asarray(sse_parts, dtype=np.float64)
         if world > 1:
             import torch
             t = torch.from_numpy(sse)

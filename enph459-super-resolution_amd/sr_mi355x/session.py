@@ -163,7 +163,8 @@ def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step
     saa = api.shift_and_add_batched(lr[None], shifts, factor)
     if row_bands:
         from . import rowband
-        band, errs, bounds = rowband.ibp_row_bands(lr, shifts, psf_kernel, saa[0], factor, n_iter, step, precision=api.get_precision())
+        band, errs, bounds = rowband.ibp_row_bands(lr, shifts, psf_kernel, saa[0], factor, n_iter, step, precision=api.get_precision(),
+                                                   iters_per_exchange=2)
         full = rowband.gather_rows(band, bounds, saa.shape[1])
         hr0 = None if full is None else torch.from_numpy(full).to(saa)
         return {"native_2x": native, "SAA": saa[0], "SAA_IBP": hr0, "LR_mean": mean_lr}, errs
