@@ -415,7 +415,7 @@ int srx_profile_get(int id, double *total_ms, long *launches)
     double tot = 0.0;
     long cnt = 0;
     for (size_t i = 0; i < pf.rec.size(); i++) {
-        if (pf.rec[i].id != id)
+        if (pf.rec[i].id != id || !pf.rec[i].ended)
             continue;
         float ms = 0.f;
         if (hipEventSynchronize(pf.rec[i].b) != hipSuccess || hipEventElapsedTime(&ms, pf.rec[i].a, pf.rec[i].b) != hipSuccess)

@@ -93,6 +93,7 @@ enum KernelId {
 struct ProfRecord {
     int id;
     hipEvent_t a, b;
+    bool ended;  // end() has recorded b (srx_profile_get skips a launch another thread is in the middle of)
 };
 
 // Thread-safe: every method takes the mutex; `on` is atomic (SRX_LAUNCH reads it without the lock); a launch owns the handle
@@ -119,7 +120,7 @@ struct Profiler {
     long long begin(int id, hipStream_t st)
     {
         std::lock_guard<std::mutex> g(mu);
-        ProfRecord r{id, take(), take()};
+        ProfRecord r{id, take(), take(), false};
         if (!r.a || !r.b) {  // a partial pair goes back to the pool
             if (r.a)
                 pool.push_back(r.a);
@@ -135,8 +136,10 @@ struct Profiler {
     {
         std::lock_guard<std::mutex> g(mu);
         const size_t i = (size_t)(h & 0xffffffffll);
-        if (h >= 0 && (unsigned)(h >> 32) == gen && i < rec.size())
+        if (h >= 0 && (unsigned)(h >> 32) == gen && i < rec.size()) {
             (void)hipEventRecord(rec[i].b, st);
+            rec[i].ended = true;
+        }
     }
     void clear()
     {

@@ -66,7 +66,7 @@ def _decode_many(paths):
     global _decoders
     if _decoders is None:
         import concurrent.futures
-        _decoders = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        _decoders = concurrent.futures.ThreadPoolExecutor(max_workers=_host_threads())
     return list(_decoders.map(_png_u8, paths))
 
 
@@ -235,6 +235,16 @@ class Prefetcher:
             self._pool.shutdown(wait=True, cancel_futures=True)
 
 
+def _host_threads():
+    """Threads for the PNG decode / encode pools: the cores this process may run on (a one-GPU share of a node is 16), at most 16 --
+    zlib and PIL release the GIL, and the files-to-files rate is bounded by exactly this work."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 PNG_COMPRESS_LEVEL = 1  # zlib level of the PNGs written (PIL's default is 6: ~4x the encode time for ~10 % smaller files; lossless either way)
 _writers, _pending = None, []
 
@@ -243,7 +253,7 @@ def _writer_pool():
     global _writers
     if _writers is None:
         import concurrent.futures
-        _writers = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        _writers = concurrent.futures.ThreadPoolExecutor(max_workers=_host_threads())
     return _writers
 
 

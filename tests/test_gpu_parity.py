@@ -239,6 +239,44 @@ def test_batch_equals_loop(prec, g_c1):
         np.testing.assert_allclose(e1[0].cpu().numpy(), errs[b].cpu().numpy(), rtol=1e-12)
 
 
+def test_profiler_from_two_threads():
+    """srx_profile_enable / srx_profile_get while another thread launches: the log is cleared under a running launch without a crash, a
+    lost record or a record landing in a recycled slot (generation-tagged handles); every launch still computes the same result."""
+    import ctypes
+    import threading
+    from sr_mi355x import _lib
+    lib = _lib.load()
+    S.set_precision("f32")
+    x = torch.from_numpy(synth.truth_image(96, 96, seed=2)).cuda().float()[None].contiguous()
+    psf = synth.gaussian_psf()
+    ref = S.blur_batched(x, psf).clone()
+    stop, bad = threading.Event(), []
+
+    def worker():
+        torch.cuda.set_device(0)
+        lr = torch.stack([S.forward_model_batched(x, psf, s, 2) for s in synth.NOMINAL_4], dim=1).contiguous()
+        while not stop.is_set():
+            hr, _ = S.ibp_batched(lr, synth.NOMINAL_4, psf, x, 2, 2, 0.5)
+            if not torch.isfinite(hr).all():
+                bad.append("non-finite")
+
+    t = threading.Thread(target=worker)
+    t.start()
+    try:
+        tot, cnt = ctypes.c_double(), ctypes.c_long()
+        for i in range(300):
+            lib.srx_profile_enable(i & 1)
+            out = S.blur_batched(x, psf)
+            assert torch.equal(out, ref)
+            for kid in range(lib.srx_profile_kernel_count()):
+                assert lib.srx_profile_get(kid, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value >= 0 and tot.value >= 0.0
+    finally:
+        stop.set()
+        t.join()
+        lib.srx_profile_enable(0)
+    assert not bad
+
+
 def test_errors_are_reported():
     from sr_mi355x import _lib
     with pytest.raises(_lib.SrxError):
