@@ -70,6 +70,7 @@ def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
         "k_ibp_patch": n_iter * (2 * hw + lrn),
         "k_ibp_ztile": 2 * hw + lrn,            # one launch = one iteration
         "k_ibp_dtile": 2 * hw + lrn,
+        "k_ibp_ctile": 2 * hw + lrn,
     }.get(name)
 
 

@@ -87,6 +87,7 @@ enum KernelId {
     KID_IBP_PATCH,
     KID_IBP_ZTILE,
     KID_IBP_DTILE,
+    KID_IBP_CTILE,
     KID_COUNT
 };
 

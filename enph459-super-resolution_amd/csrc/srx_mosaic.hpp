@@ -42,6 +42,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
                    double scale, double *errors, hipStream_t st);
 }  // namespace ztile
+namespace ctile {  // srx_ctile.hpp: delta = 0 on large frames without transposes (rows along the registers, columns along the lanes): f64, f32
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline size_t tabs_bytes(int eb, int B, int N, int H, int W);
+template <typename T>
+static int iterate(const T *hr_init, T *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, const fused::Kernel7<T> &kc,
+                   const fused::Kernel7<T> &kt, const T *Mg, const T *Cg, const T *Mu, const int *ncu, const int *nyx, int NS, int NB,
+                   const double *Vtot, Arena &ar, int H, int W, int n_iter, double step, double scale, double *errors, hipStream_t st);
+}  // namespace ctile
 namespace dtile {  // srx_dtile.hpp: a common fraction > 0 on large frames, overlapping register-resident windows, one launch per iteration
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
 static inline size_t tabs_bytes(int B, int N, int H, int W);
@@ -1059,12 +1067,14 @@ __global__ void __launch_bounds__(256)
 // one of them uses (M, C, Mu, the tap tables, the near-band lists):
 //   tiles : the blurred plane, G, per-tile MSE partials      patch : srx_patch.hpp's operand planes and tables
 //   ztile : srx_ztile.hpp's padded state / operand planes and tables
-enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3 };
+enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3, IMPL_CTILE = 4 };
 
 static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
     if (eb == 4 && !(call_flags() & (SRX_FLAG_TILES | SRX_FLAG_DIAG_WIDE_WINDOWS)) && patch::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_PATCH;
+    if (ctile::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_CTILE;
     if (ztile::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_ZTILE;
     if (dtile::eligible(eb, N, H, W, sh, k, kh, kw, f))
@@ -1091,6 +1101,8 @@ static inline size_t ws_impl(Impl im, int eb, int B, int N, int H, int W)
         return ztile::tabs_bytes(B, N, H, W);
     if (im == IMPL_DTILE)
         return dtile::tabs_bytes(B, N, H, W);
+    if (im == IMPL_CTILE)
+        return ctile::tabs_bytes(eb, B, N, H, W);
     return align_up((size_t)B * Hp * Wp * eb) + align_up((size_t)B * Hg * Wg * eb) +
            align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
@@ -1105,6 +1117,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
         m = std::max(m, ws_impl(IMPL_ZTILE, eb, B, N, H, W));
     if (eb == 4 && H >= 256 && W >= 256 && H % 4 == 0 && W % 16 == 0)
         m = std::max(m, ws_impl(IMPL_DTILE, eb, B, N, H, W));
+    if (H >= 128 && W >= 128)
+        m = std::max(m, ws_impl(IMPL_CTILE, eb, B, N, H, W));
     return ws_common(eb, B, N, H, W) + m;
 }
 
@@ -1124,7 +1138,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
     const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
-    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : "mosaic";  // what srx_last_path() reports: the branch taken
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : "mosaic";  // what srx_last_path() reports: the branch taken
     Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
     const int NS = (N + 3) & ~3;                        // slots per near-band pixel
@@ -1187,6 +1201,9 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
+    // integer HR shifts on a large frame, rows along the registers and columns along the lanes (float64; float32 on request)
+    if (impl == IMPL_CTILE)
+        return ctile::iterate<T>(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors, st);
     if constexpr (sizeof(T) == 4) {
         // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp)
         if (impl == IMPL_PATCH)

@@ -141,11 +141,18 @@ def test_ibp_frame_80_iterations_golden(prec, g_frame, case):
     saa = S.shift_and_add(lr, sh, 2)
     close(saa, saa_ref, PRIM_TOL[prec])
     hr, errs = S.ibp(lr, sh, psf, saa_ref, 2, 80, 0.5, verbose=False)
-    if prec == "f32":
-        assert S.last_path() == "ztile"
+    # float32: k_ibp_ztile (either PSF form); float64: the transpose-free k_ibp_ctile for a rank-1 PSF, the tile kernels otherwise
+    assert S.last_path() == ("ztile" if prec == "f32" else "mosaic" if case == "synth_measured_psf" else "ctile")
     close(hr, ref, IBP_TOL[prec])
     np.testing.assert_allclose(errs, eref, rtol=ERR_RTOL[prec])
     u8_close(hr, ref)
+    if case != "synth_measured_psf":  # the float32 form of the transpose-free kernel (on request: k_ibp_ztile is faster in float32)
+        S.set_precision("f32")
+        hr_c, errs_c = S.ibp_batched(np.stack(lr)[None], sh, psf, saa_ref[None], 2, 80, 0.5, flags=S.FLAG_DIAG_COLUMN_TILES)
+        assert S.last_path() == "ctile"
+        close(hr_c[0].cpu().numpy(), ref, IBP_TOL["f32"])
+        np.testing.assert_allclose(errs_c[0].cpu().numpy(), eref, rtol=ERR_RTOL["f32"])
+        S.set_precision(prec)
     if case == "synth_gauss":
         for n in (1, 10):
             hr_n, errs_n = S.ibp(lr, sh, psf, saa_ref, 2, n, 0.5, verbose=False)
@@ -337,7 +344,8 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "fused"
     close(saa_p[0].cpu().numpy(), saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
-    assert S.last_path() == (want_ibp if prec == "f32" else want)
+    want64 = "ctile" if (want_ibp == "ztile" and psf_name == "gauss") else want  # float64: the transpose-free frame kernel (rank-1 PSFs)
+    assert S.last_path() == (want_ibp if prec == "f32" else want64)
     close(hr, hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
     if want_ibp != want and prec == "f32":  # the tile kernels of srx_mosaic.hpp on the same input
@@ -390,6 +398,15 @@ def test_frame_kernel_is_deterministic():
         outs = [S.ibp_batched(lr, shifts, psf, init, f, 2, 0.5)[0].clone() for _ in range(30)]
         assert S.last_path() == "ztile"
         assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # the transpose-free frame kernel in both precisions
+    lr6 = torch.from_numpy(np.rint(rng.uniform(0, 255, (1, 5, 300, 400))) * 0.75 + 0.3).cuda()
+    init6 = torch.from_numpy(rng.uniform(0, 255, (1, 600, 800))).cuda()
+    for prec6, fl6 in (("f64", S.FLAG_AUTO), ("f32", S.FLAG_DIAG_COLUMN_TILES)):
+        S.set_precision(prec6)
+        outs = [S.ibp_batched(lr6, synth.NOMINAL_5, synth.gaussian_psf(), init6, 2, 2, 0.5, flags=fl6)[0].clone() for _ in range(12)]
+        assert S.last_path() == "ctile"
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+    S.set_precision("f32")
     # the delta != 0 frame kernel, both window shapes (round 3: the 128-bit stores behind which a vector instruction overwrote the data
     # registers -- tools/microbench/store_data_war.hip -- deviated in 12 of 12 calls of the 4 x 4 shape)
     f4, sh16 = 4, synth.phase_shifts(4)
