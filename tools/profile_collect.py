@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WL = {"c2": "c2:B=1024:f32", "c3_mono": "c3_mono:B=1:f32", "c3_mono_measured": "c3_mono_measured:B=1:f32", "c3_f4": "c3_f4:B=1:f32",
-      "c3_rgb": "c3_rgb:B=1:f32"}
+      "c3_rgb": "c3_rgb:B=1:f32", "c3_mono_f64": "c3_mono:B=1:f64"}
 
 
 def one(pattern):
@@ -58,7 +58,7 @@ def main():
             f.write(f"# rocprofv3 --kernel-trace --pmc <8 counters> (two passes), workload {wtag}, mean per launch; tools/profile_round.sh\n")
             f.write("# VALU busy = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / (GRBM_GUI_ACTIVE / 8 XCDs)   (issue cost: profiles/README.md, microbenchmark)\n")
             for k in sorted(c):
-                if not k.startswith("k_ibp") and not k.startswith("k_ztile_trace"):
+                if not k.startswith(("k_ibp", "k_ztile_trace", "k_fwd_", "k_bwd_", "k_blur_pad")):
                     continue
                 d = c[k]
                 f.write(f"{k}\n")
