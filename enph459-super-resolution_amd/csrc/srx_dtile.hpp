@@ -261,11 +261,7 @@ __global__ void __launch_bounds__(256)
                      const TileD *__restrict__ tiles, int ntiles, int *__restrict__ nn_out, uint2 *__restrict__ nrec, uint2 *__restrict__ nent, int ntabs)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, tab = blockIdx.y;
-    int ti = 0;
-    for (; ti < ntiles; ti++)  // the window this table belongs to (a handful of windows: a scan)
-        if (tiles[ti].ntab == tab)
-            break;
-    const TileD td = tiles[ti];
+    const TileD td = tiles[tab < da.tiles_x ? tab : (tab - da.tiles_x + 1) * da.tiles_x];  // top windows first, then the left ones (k_dtile_setup)
     int exy, nby, exx, nbx;
     local_axes(td, da, exy, nby, exx, nbx);
     const int nn = near_count(RX, exy, exx, nby, nbx);
@@ -299,11 +295,7 @@ __global__ void __launch_bounds__(256)
                    const TileD *__restrict__ tiles, int ntiles, float2 *__restrict__ Mn, int ntabs)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, tab = blockIdx.y, b = blockIdx.z;
-    int ti = 0;
-    for (; ti < ntiles; ti++)
-        if (tiles[ti].ntab == tab)
-            break;
-    const TileD td = tiles[ti];
+    const TileD td = tiles[tab < da.tiles_x ? tab : (tab - da.tiles_x + 1) * da.tiles_x];  // top windows first, then the left ones (k_dtile_setup)
     int exy, nby, exx, nbx;
     local_axes(td, da, exy, nby, exx, nbx);
     if (t >= near_count(RX, exy, exx, nby, nbx))
