@@ -11,6 +11,7 @@
 #include "srx_ztile.hpp"
 #include "srx_dtile.hpp"
 #include "srx_ctile.hpp"
+#include "srx_btile.hpp"
 
 using namespace srx;
 
@@ -27,7 +28,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile", "k_ibp_dtile", "k_ibp_ctile"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile", "k_ibp_dtile", "k_ibp_ctile", "k_ibp_bfwd", "k_ibp_bbwd"};
 
 // ---------------------------------------------------------------------------------------
 // composed building blocks
@@ -316,6 +317,12 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
     if (can_fuse && !(flags & SRX_FLAG_COMPOSED)) {
         if (!(flags & SRX_FLAG_PER_FRAME) && mosaic::eligible(N, h, w, sh, kh, kw, H, W, f)) {
             return mosaic::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st, &g_last_path);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (btile::eligible(4, N, h, w, sh, k, kh, kw, H, W, f)) {
+                g_last_path = "btile";
+                return btile::ibp(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
+            }
         }
         g_last_path = "fused";
         return fused::ibp<T>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, step, hr, errors, ws, wsb, st);

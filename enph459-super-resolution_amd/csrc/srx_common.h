@@ -88,6 +88,8 @@ enum KernelId {
     KID_IBP_ZTILE,
     KID_IBP_DTILE,
     KID_IBP_CTILE,
+    KID_IBP_BFWD,
+    KID_IBP_BBWD,
     KID_COUNT
 };
 
