@@ -71,6 +71,8 @@ def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
         "k_ibp_ztile": 2 * hw + lrn,            # one launch = one iteration
         "k_ibp_dtile": 2 * hw + lrn,
         "k_ibp_ctile": 2 * hw + lrn,
+        "k_ibp_bfwd": hw + 2 * lrn,             # read hr + the LR frames, write the residuals
+        "k_ibp_bbwd": lrn + 2 * hw,             # read the residuals + hr, write hr
     }.get(name)
 
 
@@ -86,9 +88,12 @@ def workload(synth, name, batch, iters):
     if name == "c3_mono_measured":  # the same frames with --psf measured (mono_cal_target/run_sr.py:114-152, 350-355): a PSF that is not rank 1
         return (2, (1536, 2048), synth.NOMINAL_5, synth.asymmetric_psf(), batch or 1, iters or 80,
                 "C3-mono, --psf measured: 1536x2048 LR -> 3072x4096, N=5 nominal shifts, asymmetric (non-separable) 7x7 PSF")
-    if name == "c3_rgb":   # rgb_cal_target/run_sr.py:49-63: 4 frames, measured shifts, f=2, 50 iterations
+    if name == "c3_rgb":   # rgb_cal_target/run_sr.py:49-63, 340-373: 4 frames, measured shifts, f=2, 50 iterations, --psf gaussian (its default)
+        return (2, (768, 1024), synth.MEASURED_4, synth.gaussian_psf(), batch or 1, iters or 50,
+                "C3-rgb: the reference's rgb_cal_target shape and defaults, 768x1024 LR -> 1536x2048, N=4 measured shifts, Gaussian PSF")
+    if name == "c3_rgb_measured":  # the same with --psf measured (rgb_cal_target/run_sr.py:128-166): a PSF that is not rank 1
         return (2, (768, 1024), synth.MEASURED_4, synth.asymmetric_psf(), batch or 1, iters or 50,
-                "C3-rgb: the reference's rgb_cal_target shape, 768x1024 LR -> 1536x2048, N=4 measured shifts, asymmetric PSF")
+                "C3-rgb, --psf measured: 768x1024 LR -> 1536x2048, N=4 measured shifts, asymmetric (non-separable) 7x7 PSF")
     if name == "c3_f4":    # "plus f=4 variant 768x1024 -> 3072x4096"
         return (4, (768, 1024), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1, iters or 80,
                 "C3-f4: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all 4x4 sub-pixel phases), Gaussian PSF")
@@ -284,7 +289,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: 1024 patches for c2, 1 frame for c3_*)")
     ap.add_argument("--iters", type=int, default=0, help="IBP iterations (default: the reference's 80; 50 for c3_rgb)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_f4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_rgb_measured", "c3_f4"],
                     help="c2 (default, the headline): 1024 x4 patches, N=16 phases; c3_mono / c3_rgb: the reference's own "
                          "full-frame shapes (mono_cal_target N=5 nominal f=2 3072x4096; rgb_cal_target N=4 measured f=2 1536x2048); "
                          "c3_f4: the x4 variant of SURVEY 8d, 768x1024 -> 3072x4096, all 16 phases")
@@ -361,7 +366,8 @@ def main():
         for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c3_mono", "c3_mono", "f32", None), ("c3_mono_f64", "c3_mono", "f64", None),
                                       ("c3_rgb", "c3_rgb", "f32", None),
                                       ("c3_f4", "c3_f4", "f32", None), ("c3_mono_x8", "c3_mono", "f32", 8),
-                                      ("c3_mono_measured", "c3_mono_measured", "f32", None), ("c3_rgb_x8", "c3_rgb", "f32", 8)):
+                                      ("c3_mono_measured", "c3_mono_measured", "f32", None), ("c3_rgb_x8", "c3_rgb", "f32", 8),
+                                      ("c3_rgb_measured", "c3_rgb_measured", "f32", None)):
             lw = workload(synth, wname, lb if lb else (args.batch if wname == "c2" and args.batch else None), args.iters if wname == "c2" else None)
             r = measure(S, synth, lib, lw, lprec, 2, 1, 7000)
             legs[tag] = {"workload": r["desc"], "dtype": lprec, "batch": r["B"], "n_iter": r["n_iter"], "path": r["path"],

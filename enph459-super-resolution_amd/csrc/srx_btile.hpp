@@ -48,6 +48,7 @@ struct BFrame {  // 20 words
 };
 struct BArgs {
     int N, h, w, H, W, nwx, nwy;
+    int oyf_min, oyf_max, oyb_min, oyb_max;  // range of the frames' row tap origins (which blocks need no row checks)
     float sn;              // step / N
     float kby[8], kbx[8];  // forward blur (correlation) weights, times kq
     float kty[8], ktx[8];  // backward blur (flipped kernel) weights
@@ -176,8 +177,149 @@ __device__ __forceinline__ void hfir_up(float (&A)[64], const float (&g)[64], co
 
 __device__ __forceinline__ int asr1(int x) { return x >> 1; }  // floor(x / 2)
 
+constexpr int VOFF_OUT = (int)0x80000000;  // a lane offset that stays out of every descriptor's range when a row offset (< 2^30) is added
+
+// LR rows [I0, I1) of the forward pair step: sim = V-FIR of t with this lane's five weights, err = lr - sim (stored), sq += err^2.
+// CHK: rows are owned where ilo <= i < ilo + nrow (per lane: windows on the first / last image rows); otherwise every row of the range is.
+template <int I0, int I1, bool CHK>
+__device__ __forceinline__ void fwd_rows_load(float (&lv)[32], __amdgpu_buffer_rsrc_t rs_lr, int vbase, int w4, int ilo, unsigned nrow)
+{
+#pragma unroll
+    for (int i = I0; i < I1; i++) {
+        int voff = vbase + i * w4;
+        if (CHK)
+            voff = (unsigned)(i - ilo) < nrow ? voff : VOFF_OUT;
+        lv[i] = fused::buf_load<float>(rs_lr, voff, 0);
+    }
+}
+template <int I0, int I1, bool CHK>
+__device__ __forceinline__ void fwd_rows(const float (&t)[64], const float (&th)[3], const float (&wv)[5], const float (&lv)[32],
+                                         __amdgpu_buffer_rsrc_t rs_er, int vbase, int w4, int ilo, unsigned nrow, float &sq)
+{
+#pragma unroll
+    for (int i = I0; i < I1; i++) {
+        auto T = [&](int q) -> float { return q < 64 ? t[q < 64 ? q : 0] : th[q < 64 ? 0 : q - 64]; };
+        float sim = wv[0] * T(2 * i);
+#pragma unroll
+        for (int q = 1; q < 5; q++)
+            sim = fmaf(wv[q], T(2 * i + q), sim);
+        float e = lv[i] - sim;
+        int voff = vbase + i * w4;
+        if (CHK) {
+            const bool ok = (unsigned)(i - ilo) < nrow;
+            voff = ok ? voff : VOFF_OUT;
+            e = ok ? e : 0.f;
+        }
+        fused::buf_store<float>(e, rs_er, voff, 0);  // out of the descriptor's range: dropped
+        sq = fmaf(e, e, sq);
+    }
+}
+
+// residual rows E[0..33] of the backward pair step.  CLAMP_LO: rows above the image repeat LR row 0 (first window row);
+// CHECK_HI: rows past the last read 0.
+template <bool CLAMP_LO, bool CHECK_HI>
+__device__ __forceinline__ void bwd_rows_load(float (&E)[34], __amdgpu_buffer_rsrc_t rs_er, int vrow0, int ibase, int w4, int h)
+{
+#pragma unroll
+    for (int m = 0; m < 34; m++) {
+        const int row = ibase + m;
+        int voff = vrow0 + (CLAMP_LO ? max(row, 0) : row) * w4;
+        if (CHECK_HI)
+            voff = row < h ? voff : VOFF_OUT;
+        E[m] = fused::buf_load<float>(rs_er, voff, 0);
+    }
+}
+
+// ---- the state plane: four image rows interleaved, S[b][row >> 2][column][row & 3] (H4 = ceil(H / 4) row quads; rows past H hold 0).
+// A block's rows (column layout: lane = column) then travel 16 bytes per lane and instruction -- a CU issues a vector memory instruction
+// every ~9 cycles whatever its width (srx_patch.hpp), and 64 one-word loads per wave were a tenth of the forward kernel.  A block starts
+// at a padded row = 2 (mod 4): register y is image row Pb - 12 + y, the quads start at y = 2 (mod 4); y = 0, 1 and y = 62, 63 are halves
+// of quads shared with the neighbour blocks (8-byte accesses).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+using patch::u32x4;
+// quad q of the block (q = -1: the half quad of y = 0, 1; 0..14: y = 2 + 4 q ..; 15: the half quad of y = 62, 63)
+template <int Q> __device__ __forceinline__ void quad_load(float (&a)[64], __amdgpu_buffer_rsrc_t rs, int vq0, int W16)
+{
+    if (Q == -1) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vq0 - W16 + 8, 0, 0);
+        a[0] = __uint_as_float(v.x), a[1] = __uint_as_float(v.y);
+    } else if (Q == 15) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vq0 + 15 * W16, 0, 0);
+        a[62] = __uint_as_float(v.x), a[63] = __uint_as_float(v.y);
+    } else {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vq0 + Q * W16, 0, 0);
+        a[2 + 4 * Q] = __uint_as_float(v.x), a[3 + 4 * Q] = __uint_as_float(v.y), a[4 + 4 * Q] = __uint_as_float(v.z), a[5 + 4 * Q] = __uint_as_float(v.w);
+    }
+}
+template <int Q0, int Q1> __device__ __forceinline__ void quads_load(float (&a)[64], __amdgpu_buffer_rsrc_t rs, int vq0, int W16)
+{
+    if constexpr (Q0 < Q1) {
+        quad_load<Q0>(a, rs, vq0, W16);
+        quads_load<Q0 + 1, Q1>(a, rs, vq0, W16);
+    }
+}
+// the update hr <- clip(hr + sn corr) on quads [Q0, Q1) of a block; rows from `ymax` on lie past the image and keep their zeros
+template <int Q> __device__ __forceinline__ void quad_update(const float (&r)[64], const float (&hv)[64], __amdgpu_buffer_rsrc_t rs, int vq0, int W16, float sn,
+                                                            int ymax)
+{
+    auto U = [&](int y) -> float { return y < ymax ? __builtin_amdgcn_fmed3f(fmaf(r[y], sn, hv[y]), 0.f, 255.f) : 0.f; };
+    if (Q == -1) {
+        const u32x2 v = {__float_as_uint(U(0)), __float_as_uint(U(1))};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vq0 - W16 + 8, 0, 0);
+    } else if (Q == 15) {
+        const u32x2 v = {__float_as_uint(U(62)), __float_as_uint(U(63))};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vq0 + 15 * W16, 0, 0);
+    } else {
+        const u32x4 v = {__float_as_uint(U(2 + 4 * Q)), __float_as_uint(U(3 + 4 * Q)), __float_as_uint(U(4 + 4 * Q)), __float_as_uint(U(5 + 4 * Q))};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, vq0 + Q * W16, 0, 0);  // (no scalar offset: srx_patch.hpp's st4 note)
+    }
+}
+template <int Q0, int Q1> __device__ __forceinline__ void quads_update(const float (&r)[64], const float (&hv)[64], __amdgpu_buffer_rsrc_t rs, int vq0, int W16,
+                                                                      float sn, int ymax)
+{
+    if constexpr (Q0 < Q1) {
+        quad_update<Q0>(r, hv, rs, vq0, W16, sn, ymax);
+        quads_update<Q0 + 1, Q1>(r, hv, rs, vq0, W16, sn, ymax);
+    }
+}
+
+// image plane <-> state plane.  grid (ceil(W / 256), H4, B)
+__global__ void __launch_bounds__(256) k_btile_copy_in(const float *__restrict__ img, int H, int W, int H4, float *__restrict__ S)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y, b = blockIdx.z;
+    if (x >= W)
+        return;
+    const float *src = img + (size_t)b * H * W + x;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        v[c] = 4 * q + c < H ? src[(size_t)(4 * q + c) * W] : 0.f;
+    reinterpret_cast<float4 *>(S)[((size_t)b * H4 + q) * W + x] = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ void __launch_bounds__(256) k_btile_copy_out(const float *__restrict__ S, int H, int W, int H4, float *__restrict__ img)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y, b = blockIdx.z;
+    if (x >= W)
+        return;
+    const float4 v4 = reinterpret_cast<const float4 *>(S)[((size_t)b * H4 + q) * W + x];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float *dst = img + (size_t)b * H * W + x;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (4 * q + c < H)
+            dst[(size_t)(4 * q + c) * W] = v[c];
+}
+// the frame table where the lanes can index it (by-value kernel arguments indexed per lane become a scalar-load loop over the lanes)
+__global__ void k_btile_params(BArgs A, int *__restrict__ dst)
+{
+    const int *src = reinterpret_cast<const int *>(&A.fr[0]);
+    for (int i = threadIdx.x; i < MAXF * 20; i += blockDim.x)
+        dst[i] = src[i];
+}
+
 // window geometry shared by the two kernels
 template <int NBY, int NBX> struct Geo {
+    static_assert(NBY >= 2 && NBX >= 2, "the first and the last block of a line are different blocks");
     static constexpr int OWNY = 64 * NBY - HLO - HHI, OWNX = 64 * NBX - HLO - HHI;
 };
 
@@ -186,8 +328,8 @@ template <int NBY, int NBX> struct Geo {
 // =========================================================================================================================
 template <int NBY, int NBX>
 __global__ void __launch_bounds__(NBY *NBX * 64)
-    k_ibp_bfwd(const float *__restrict__ hr, const float *__restrict__ lr, float *__restrict__ err, BArgs A, double *__restrict__ epart,
-               double scale)
+    k_ibp_bfwd(const float *__restrict__ S, const float *__restrict__ lr, float *__restrict__ err, BArgs A, const int *__restrict__ frtab,
+               double *__restrict__ epart, double scale)
 {
     using L = Lds<NBY, NBX>;
     __shared__ float lds[L::WORDS];
@@ -203,36 +345,38 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
     float *edge = lds + L::OFF_EDGE;
     int *frt = reinterpret_cast<int *>(lds + L::OFF_FR);
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
-    {  // the frame table where a lane can index it
-        const int *src = reinterpret_cast<const int *>(&A.fr[0]);
-        for (int i = tid; i < N * 20; i += L::NT)
-            frt[i] = src[i];
-    }
+    for (int i = tid; i < N * 20; i += L::NT)  // the frame table where a lane can index it
+        frt[i] = frtab[i];
+    SRX_PSTAMP(0);
     // ================= column layout: lane = column Xb + lane, a[i] = row Pb + i =================
     float a[64];
     {
-        const __amdgpu_buffer_rsrc_t rs = fused::plane_rsrc(hr + (size_t)b * H * W, (size_t)H * W);
+        const int H4 = (H + 3) >> 2;
+        const __amdgpu_buffer_rsrc_t rs = fused::plane_rsrc(S + (size_t)b * H4 * W * 4, (size_t)H4 * W * 4);
         const int col = Xb + lane - SRX_NPAD;
         const bool colok = col >= 0 && col < W;
-        const int r0 = Pb - SRX_NPAD;
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            const int voff = colok ? ((r0 + i) * W + col) * 4 : -1;  // a row outside the image is out of the descriptor's range: reads 0
-            a[i] = (r0 + i >= 0 && r0 + i < H) ? fused::buf_load<float>(rs, voff, 0) : 0.f;
-        }
+        // a row quad outside the plane is out of the descriptor's range (a negative offset wraps past it): reads 0, fftconvolve's padding
+        const int W16 = W * 16, vq0 = colok ? (((Pb - SRX_NPAD + 2) >> 2) * W + col) * 16 : VOFF_OUT;
+        quads_load<-1, 16>(a, rs, vq0, W16);
     }
+    SRX_PSTAMP(1);
     blur_block(a, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_A, lane, ld8(A.kby));
+    SRX_PSTAMP(2);
     edge_replicate(a, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
     float hi[3];
     prefilter_block(a, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_B, lane, hi);
+    SRX_PSTAMP(3);
     __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
     float c[64];
     transpose64(a, c, Rown, lane);
+    SRX_PSTAMP(4);
     // ================= row layout: lane = row Pb + lane, c[j] = column Xb + j =================
     blur_block(c, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_A, lane, ld8(A.kbx));
+    SRX_PSTAMP(5);
     edge_replicate(c, Xb, W + SRX_NPAD - 1, R0x + 64 * NBX - 1 > W + SRX_NPAD - 1, edge + 64 * s + lane);
     prefilter_block(c, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_B, lane, hi);
     __syncthreads();
+    SRX_PSTAMP(6);
     // ================= pairs of frames =================
     const int Ya = R0y + HLO, Yb = R0y + 64 * NBY - HHI, Xa = R0x + HLO, Xe = R0x + 64 * NBX - HHI;  // owned tap origins
     const int kk = lane >> 5, jl = lane & 31;
@@ -263,8 +407,10 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
                     hfir_dec<0, 1>(c, hi, w0, w1, w2, w3, sv);
             }
         }
+        SRX_PSTAMP(7);
         float t[64];
         transpose64(sv, t, Rown, lane);
+        SRX_PSTAMP(8);
         // ---- lane = (frame kk of the pair, LR column jl of the block), t[y] = row Pb + y
         const int k = 2 * kp + kk;
         const bool kok = k < N;
@@ -282,33 +428,40 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         const bool lane_ok = kok && X >= Xa && X < Xe && jg >= 0 && jg < w;
         const int ilo = max(asr1(Ya - Pb - py + 1), -ibase), ihi = min(asr1(Yb - 1 - Pb - py) + 1, h - ibase);
         const unsigned nrow = lane_ok ? (unsigned)max(ihi - ilo, 0) : 0u;
-        const int vbase = ((k * h + ibase) * w + jg) * 4;
+        const int vbase = lane_ok ? ((k * h + ibase) * w + jg) * 4 : VOFF_OUT, w4 = w * 4;
+        // owned rows of an interior block: i in [I0, I1) whatever the frame (Ya - Pb and Yb - Pb are even); blocks whose LR rows
+        // may leave the image check every row
+        constexpr int IA0 = HLO / 2, IB1 = 32 * NBY - HHI / 2 - 32 * (NBY - 1);
+        const bool interior = asr1(Pb - A.oyf_max) >= 0 && asr1(Pb + 1 - A.oyf_min) + 32 <= h;
+        const int rowsel = !interior ? 0 : (s == 0 ? 1 : (s == NBY - 1 ? 2 : 3));
         float lv[32];
-#pragma unroll
-        for (int i = 0; i < 32; i++)
-            lv[i] = (unsigned)(i - ilo) < nrow ? fused::buf_load<float>(rs_lr, vbase + i * w * 4, 0) : 0.f;
+        if (rowsel == 0)
+            fwd_rows_load<0, 32, true>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else if (rowsel == 1)
+            fwd_rows_load<IA0, 32, false>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else if (rowsel == 2)
+            fwd_rows_load<0, IB1, false>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else
+            fwd_rows_load<0, 32, false>(lv, rs_lr, vbase, w4, ilo, nrow);
         // the three rows past the block: the block below holds them
         float *ex = lds + L::OFF_EX + wave * 512 + (kp & 1) * 256;
         const float *exd = lds + L::OFF_EX + (wave + NBX) * 512 + (kp & 1) * 256;
         ex[lane] = t[0], ex[64 + lane] = t[1], ex[128 + lane] = t[2];
         __syncthreads();
+        SRX_PSTAMP(9);
         float th[3] = {0.f, 0.f, 0.f};
         if (s < NBY - 1)
             th[0] = exd[lane], th[1] = exd[64 + lane], th[2] = exd[128 + lane];
-#pragma unroll
-        for (int i = 0; i < 32; i++) {
-            auto T = [&](int q) -> float { return q < 64 ? t[q < 64 ? q : 0] : th[q < 64 ? 0 : q - 64]; };
-            float sim = wv[0] * T(2 * i);
-#pragma unroll
-            for (int q = 1; q < 5; q++)
-                sim = fmaf(wv[q], T(2 * i + q), sim);
-            const float e = lv[i] - sim;
-            if ((unsigned)(i - ilo) < nrow) {
-                fused::buf_store<float>(e, rs_er, vbase + i * w * 4, 0);
-                sq = fmaf(e, e, sq);
-            }
-        }
+        if (rowsel == 0)
+            fwd_rows<0, 32, true>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+        else if (rowsel == 1)
+            fwd_rows<IA0, 32, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+        else if (rowsel == 2)
+            fwd_rows<0, IB1, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+        else
+            fwd_rows<0, 32, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
     }
+    SRX_PSTAMP(10);
     if (epart) {
         const double ws = wave_sum((double)sq);
         if (lane == 0)
@@ -330,8 +483,8 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
 // =========================================================================================================================
 template <int NBY, int NBX>
 __global__ void __launch_bounds__(NBY *NBX * 64)
-    k_ibp_bbwd(const float *__restrict__ err, const float *__restrict__ hr_in, float *__restrict__ hr_out, BArgs A,
-               const double *__restrict__ epart, double *__restrict__ errors, int errors_stride)
+    k_ibp_bbwd(const float *__restrict__ err, float *__restrict__ S, BArgs A, const int *__restrict__ frtab, const double *__restrict__ epart,
+               double *__restrict__ errors, int errors_stride)
 {
     using L = Lds<NBY, NBX>;
     __shared__ float lds[L::WORDS];
@@ -346,11 +499,8 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
     const float *Rup = lds + (wave - NBX) * RW, *Rdn = lds + (wave + NBX) * RW, *Rlf = lds + (wave - 1) * RW, *Rrt = lds + (wave + 1) * RW;
     int *frt = reinterpret_cast<int *>(lds + L::OFF_FR);
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
-    {
-        const int *src = reinterpret_cast<const int *>(&A.fr[0]);
-        for (int i = tid; i < N * 20; i += L::NT)
-            frt[i] = src[i];
-    }
+    for (int i = tid; i < N * 20; i += L::NT)
+        frt[i] = frtab[i];
     __syncthreads();
     if (errors && wx == 0 && wy == 0) {  // MSE trace of this iteration: the forward windows' sums in a fixed order
         const int nwin = A.nwx * A.nwy;
@@ -370,6 +520,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
             errors[(size_t)b * errors_stride] = tsum;
         }
     }
+    SRX_PSTAMP(12);
     const int kk = lane >> 5, jl = lane & 31;
     const __amdgpu_buffer_rsrc_t rs_er = fused::plane_rsrc(err + (size_t)b * N * h * w, (size_t)N * h * w);
     float v[64];  // row layout: lane = row Pb + lane, v[x] = column Xb + x
@@ -386,16 +537,20 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
             const int oy = fk[2], ox = fk[3];
             const int py = (oy + Pb) & 1, px = (ox + Xb) & 1;
             const int ibase = asr1(Pb + oy + py - SRX_NPAD), jg = asr1(Xb + ox + px - SRX_NPAD) + jl;
-            const bool lane_ok = kok && jg < w;
-            const int jc = max(jg, 0);  // the left pad repeats LR column 0
+            const bool lane_ok = kok && jg < w;  // (a lane past the last LR column, a frame past the last: zero weights)
+            const int jc = min(max(jg, 0), w - 1);  // the left pad repeats LR column 0
+            const int w4 = w * 4, vrow0 = ((kok ? k : 0) * h * w + jc) * 4;
             float E[34];
-#pragma unroll
-            for (int m = 0; m < 34; m++) {
-                const int row = ibase + m;
-                const int voff = ((k * h + max(row, 0)) * w + jc) * 4;  // the top pad repeats LR row 0; past the last row: zeros
-                E[m] = (lane_ok && row < h) ? fused::buf_load<float>(rs_er, voff, 0) : 0.f;
-            }
-            const float y0 = __int_as_float(fk[12]), y1 = __int_as_float(fk[13]), y2 = __int_as_float(fk[14]), y3 = __int_as_float(fk[15]);
+            // the top pad repeats LR row 0 (first window row); rows past the last are zeros (last window rows)
+            const bool lo_ok = asr1(Pb + A.oyb_min - SRX_NPAD) >= 0, hi_ok = asr1(Pb + A.oyb_max + 1 - SRX_NPAD) + 34 <= h;
+            if (lo_ok && hi_ok)
+                bwd_rows_load<false, false>(E, rs_er, vrow0, ibase, w4, h);
+            else if (hi_ok)
+                bwd_rows_load<true, false>(E, rs_er, vrow0, ibase, w4, h);
+            else
+                bwd_rows_load<true, true>(E, rs_er, vrow0, ibase, w4, h);
+            const float y0 = lane_ok ? __int_as_float(fk[12]) : 0.f, y1 = lane_ok ? __int_as_float(fk[13]) : 0.f,
+                        y2 = lane_ok ? __int_as_float(fk[14]) : 0.f, y3 = lane_ok ? __int_as_float(fk[15]) : 0.f;
             const float a0 = py ? y1 : y0, a1 = py ? y3 : y2;
             const float b0 = py ? y0 : 0.f, b1 = py ? y2 : y1, b2 = py ? 0.f : y3;
 #pragma unroll
@@ -417,13 +572,16 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
                 }
             }
         }
+        SRX_PSTAMP(13);
         float g[64];
         transpose64(uu, g, Rown, lane);
+        SRX_PSTAMP(14);
         // ---- row layout: g[32 half + t] = LR column t of the block of frame 2 kp + half; columns 32, 33 from the right neighbour
         float *ex = lds + L::OFF_EX + wave * 512 + (kp & 1) * 256;
         const float *exr = lds + L::OFF_EX + (wave + 1) * 512 + (kp & 1) * 256;
         ex[lane] = g[0], ex[64 + lane] = g[1], ex[128 + lane] = g[32], ex[192 + lane] = g[33];
         __syncthreads();
+        SRX_PSTAMP(15);
         float gh0[2] = {0.f, 0.f}, gh1[2] = {0.f, 0.f};
         if (u < NBX - 1)
             gh0[0] = exr[lane], gh0[1] = exr[64 + lane], gh1[0] = exr[128 + lane], gh1[1] = exr[192 + lane];
@@ -462,37 +620,50 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
             }
         }
     }
+    SRX_PSTAMP(16);
     __syncthreads();  // the exchange buffers and the slots are free
     float hi[3];
     prefilter_block(v, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_B, lane, hi);
+    SRX_PSTAMP(17);
     zero_outside(v, Xb, W + SRX_NPAD - 1);
     blur_block(v, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_A, lane, ld8(A.ktx));
     __syncthreads();
+    SRX_PSTAMP(18);
     float r[64];
     transpose64(v, r, Rown, lane);
+    SRX_PSTAMP(19);
     // ================= column layout: lane = column Xb + lane, r[y] = row Pb + y =================
     const int col = Xb + lane - SRX_NPAD;
     const bool col_ok = Xb + lane >= R0x + HLO && Xb + lane < R0x + 64 * NBX - HHI && col >= 0 && col < W;
-    const int ylo = max(R0y + HLO, SRX_NPAD) - Pb, yhi = min(R0y + 64 * NBY - HHI, H + SRX_NPAD) - Pb;  // owned rows of the image, block-local
+    // owned rows of the block: [HLO, 64) in the first, [0, 64 - HHI) in the last -- whole row quads of the state plane (the window's
+    // owned span starts at a multiple of 4 image rows); rows above the image are out of the descriptor's range, rows past it keep 0
+    const int H4 = (H + 3) >> 2, W16 = W * 16, vq0 = col_ok ? (((Pb - SRX_NPAD + 2) >> 2) * W + col) * 16 : VOFF_OUT;
+    const int ymax = H + SRX_NPAD - Pb;
+    const __amdgpu_buffer_rsrc_t rs_s = fused::plane_rsrc(S + (size_t)b * H4 * W * 4, (size_t)H4 * W * 4);
+    constexpr int QA = (HLO - 2) / 4, QB = (64 - HHI - 2) / 4;
+    static_assert((HLO - 2) % 4 == 0 && (64 - HHI - 2) % 4 == 0, "owned spans are whole row quads");
     float hv[64];
-    {
-        const __amdgpu_buffer_rsrc_t rs = fused::plane_rsrc(hr_in + (size_t)b * H * W, (size_t)H * W);
-#pragma unroll
-        for (int y = 0; y < 64; y++)
-            hv[y] = (col_ok && y >= ylo && y < yhi) ? fused::buf_load<float>(rs, ((Pb + y - SRX_NPAD) * W + col) * 4, 0) : 0.f;
-    }
+    if (s == 0)
+        quads_load<QA, 16>(hv, rs_s, vq0, W16);
+    else if (s == NBY - 1)
+        quads_load<-1, QB>(hv, rs_s, vq0, W16);
+    else
+        quads_load<-1, 16>(hv, rs_s, vq0, W16);
     prefilter_block(r, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_B, lane, hi);
+    SRX_PSTAMP(20);
     zero_outside(r, Pb, H + SRX_NPAD - 1);
     blur_block(r, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_A, lane, ld8(A.kty));
+    SRX_PSTAMP(21);
     {
-        const __amdgpu_buffer_rsrc_t rs = fused::plane_rsrc(hr_out + (size_t)b * H * W, (size_t)H * W);
         const float sn = A.sn;
-#pragma unroll
-        for (int y = 0; y < 64; y++) {
-            if (col_ok && y >= ylo && y < yhi)
-                fused::buf_store<float>(__builtin_amdgcn_fmed3f(fmaf(r[y], sn, hv[y]), 0.f, 255.f), rs, ((Pb + y - SRX_NPAD) * W + col) * 4, 0);
-        }
+        if (s == 0)
+            quads_update<QA, 16>(r, hv, rs_s, vq0, W16, sn, ymax);
+        else if (s == NBY - 1)
+            quads_update<-1, QB>(r, hv, rs_s, vq0, W16, sn, ymax);
+        else
+            quads_update<-1, 16>(r, hv, rs_s, vq0, W16, sn, ymax);
     }
+    SRX_PSTAMP(22);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
@@ -513,7 +684,8 @@ static inline bool eligible(int elem_bytes, int N, int h, int w, const double *s
 static inline size_t ws_bytes(int B, int N, int h, int w, int H, int W)
 {
     const int nwy = cdiv(H + 2 * SRX_NPAD, Geo<2, 2>::OWNY), nwx = cdiv(W + 2 * SRX_NPAD, Geo<2, 2>::OWNX);
-    return align_up((size_t)B * N * h * w * 4) + align_up((size_t)B * nwy * nwx * sizeof(double));
+    return align_up((size_t)B * N * h * w * 4) + align_up((size_t)B * nwy * nwx * sizeof(double)) + align_up((size_t)B * ((H + 3) / 4) * W * 16) +
+           align_up(MAXF * 20 * sizeof(int));
 }
 
 static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
@@ -528,9 +700,12 @@ static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, co
     Arena ar(ws, wsb);
     float *err = ar.take<float>((size_t)B * N * h * w);
     double *epart = ar.take<double>((size_t)B * A.nwy * A.nwx);
+    const int H4 = (H + 3) / 4;
+    float *S = ar.take<float>((size_t)B * H4 * W * 4);  // the state plane, four rows interleaved
+    int *frtab = ar.take<int>(MAXF * 20);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    if (A.nwy > 65535 || B > 65535)
+    if (A.nwy > 65535 || B > 65535 || H4 > 65535)
         return SRX_E_UNSUPPORTED;
     const double kq = -6.0 * patch::ZD;
     fused::Kernel7<float> kc, kt;
@@ -541,6 +716,7 @@ static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, co
         A.kby[i] = (float)(kq * (double)kc.cy[i]), A.kbx[i] = (float)(kq * (double)kc.cx[i]);
         A.kty[i] = kt.cy[i], A.ktx[i] = kt.cx[i];
     }
+    A.oyf_min = A.oyb_min = 1 << 20, A.oyf_max = A.oyb_max = -(1 << 20);
     for (int q = 0; q < MAXF; q++) {
         BFrame &f = A.fr[q];
         f.oyf = f.oxf = f.oyb = f.oxb = 0;
@@ -553,6 +729,8 @@ static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, co
         fused::make_tap<double>(-dy, -dx, SRX_NPAD, tf);  // forward_model: x = 2 i - d + 12 (srx_fused.hpp)
         fused::make_tap<double>(+dy, +dx, 0, tb);         // back_project: the padded FIR reads Z[p + floor(d) - 1 + a]
         f.oyf = tf.oy, f.oxf = tf.ox, f.oyb = tb.oy, f.oxb = tb.ox;
+        A.oyf_min = std::min(A.oyf_min, f.oyf), A.oyf_max = std::max(A.oyf_max, f.oyf);
+        A.oyb_min = std::min(A.oyb_min, f.oyb), A.oyb_max = std::max(A.oyb_max, f.oyb);
         for (int i = 0; i < 4; i++) {
             f.wyf[i] = (float)tf.wy[i], f.wxf[i] = (float)tf.wx[i];
             f.wyb[i] = (float)(kq * tb.wy[i]), f.wxb[i] = (float)(kq * tb.wx[i]);
@@ -562,12 +740,20 @@ static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, co
     if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SRX_E_HIP;
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
+    if (n_iter == 0)
+        return SRX_OK;
+    hipLaunchKernelGGL(k_btile_params, dim3(1), dim3(64), 0, st, A, frtab);
+    SRX_CHECK_LAUNCH();
+    const dim3 cgrid(cdiv(W, 256), H4, B);
+    hipLaunchKernelGGL(k_btile_copy_in, cgrid, dim3(256), 0, st, hr_init, H, W, H4, S);
+    SRX_CHECK_LAUNCH();
     const dim3 grid(A.nwx, A.nwy, B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
-        const float *cur = it == 0 ? hr_init : hr;
-        SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX>), grid, blk, 0, st, cur, lr, err, A, errors ? epart : nullptr, scale);
-        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX>), grid, blk, 0, st, err, cur, hr, A, epart, errors ? errors + it : nullptr, n_iter);
+        SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
+        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX>), grid, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
     }
+    hipLaunchKernelGGL(k_btile_copy_out, cgrid, dim3(256), 0, st, S, H, W, H4, hr);
+    SRX_CHECK_LAUNCH();
     return SRX_OK;
 }
 
