@@ -36,9 +36,15 @@ using patch::RW;
 using patch::transpose64;
 using patch::ZP;
 
+#ifndef SRX_BT_PREFETCH
+#define SRX_BT_PREFETCH 1  // the forward kernel's LR samples requested ahead of the H-FIR and the transpose
+#endif
+#ifndef SRX_BT_MINB
+#define SRX_BT_MINB 2  // workgroups per CU the register allocation aims at
+#endif
 constexpr int HLO = 14, HHI = 18;  // halo before / after the owned span
 constexpr int MAXF = 16;           // frames per call
-constexpr int SLOT_A = 0, SLOT_B = 1024;  // exchange slots inside a wave's transpose region (<= 6 x 64 words each)
+constexpr int SLOT_A = 0, SLOT_B = 384, XW = 640;  // a wave's exchange slots: blur (6 x 64 words), prefilter (4 x 64)
 
 struct BFrame {  // 20 words
     int oyf, oxf;  // forward: sim[i, j] = sum wyf[a] wxf[b] c[2 i + oyf + a, 2 j + oxf + b] (padded coordinates)
@@ -58,7 +64,9 @@ struct BArgs {
 template <int NBY, int NBX> struct Lds {
     static constexpr int NW = NBY * NBX, NT = NW * 64;
     static constexpr int OFF_EX = NW * RW;                   // per wave 2 x 256 words: halo registers of the pair loop, double buffered
-    static constexpr int OFF_EDGE = OFF_EX + NW * 512;       // replicated edge sample, one per line: [max(NBY, NBX) * 64]
+    static constexpr int OFF_SL = OFF_EX + NW * 512;         // per wave XW words: the exchange slots of the blurs and the prefilters (outside the
+                                                             // transpose regions: a wave may transpose while a neighbour still reads its slots)
+    static constexpr int OFF_EDGE = OFF_SL + NW * XW;        // replicated edge sample, one per line: [max(NBY, NBX) * 64]
     static constexpr int OFF_FR = OFF_EDGE + (NBY > NBX ? NBY : NBX) * 64;
     static constexpr int OFF_PART = OFF_FR + MAXF * 20;
     static constexpr int WORDS = OFF_PART + 2 * NW + 2;
@@ -181,19 +189,20 @@ constexpr int VOFF_OUT = (int)0x80000000;  // a lane offset that stays out of ev
 
 // LR rows [I0, I1) of the forward pair step: sim = V-FIR of t with this lane's five weights, err = lr - sim (stored), sq += err^2.
 // CHK: rows are owned where ilo <= i < ilo + nrow (per lane: windows on the first / last image rows); otherwise every row of the range is.
-template <int I0, int I1, bool CHK>
-__device__ __forceinline__ void fwd_rows_load(float (&lv)[32], __amdgpu_buffer_rsrc_t rs_lr, int vbase, int w4, int ilo, unsigned nrow)
+template <int I0, int I1, bool CHK, int LVN>
+__device__ __forceinline__ void fwd_rows_load(float (&lv)[LVN], __amdgpu_buffer_rsrc_t rs_lr, int vbase, int w4, int ilo, unsigned nrow)
 {
+    static_assert(I1 - I0 <= LVN, "lv holds rows I0 .. I1 - 1 from its first element on");
 #pragma unroll
     for (int i = I0; i < I1; i++) {
         int voff = vbase + i * w4;
         if (CHK)
             voff = (unsigned)(i - ilo) < nrow ? voff : VOFF_OUT;
-        lv[i] = fused::buf_load<float>(rs_lr, voff, 0);
+        lv[i - I0] = fused::buf_load<float>(rs_lr, voff, 0);
     }
 }
-template <int I0, int I1, bool CHK>
-__device__ __forceinline__ void fwd_rows(const float (&t)[64], const float (&th)[3], const float (&wv)[5], const float (&lv)[32],
+template <int I0, int I1, bool CHK, int LVN>
+__device__ __forceinline__ void fwd_rows(const float (&t)[64], const float (&th)[3], const float (&wv)[5], const float (&lv)[LVN],
                                          __amdgpu_buffer_rsrc_t rs_er, int vbase, int w4, int ilo, unsigned nrow, float &sq)
 {
 #pragma unroll
@@ -203,7 +212,7 @@ __device__ __forceinline__ void fwd_rows(const float (&t)[64], const float (&th)
 #pragma unroll
         for (int q = 1; q < 5; q++)
             sim = fmaf(wv[q], T(2 * i + q), sim);
-        float e = lv[i] - sim;
+        float e = lv[i - I0] - sim;
         int voff = vbase + i * w4;
         if (CHK) {
             const bool ok = (unsigned)(i - ilo) < nrow;
@@ -327,7 +336,7 @@ template <int NBY, int NBX> struct Geo {
 // forward: err[b, k, i, j] = lr - (F_k P pad B hr)[2 i, 2 j];  epart[b, window] = sum err^2 * scale.  grid (nwx, nwy, B)
 // =========================================================================================================================
 template <int NBY, int NBX>
-__global__ void __launch_bounds__(NBY *NBX * 64)
+__global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bfwd(const float *__restrict__ S, const float *__restrict__ lr, float *__restrict__ err, BArgs A, const int *__restrict__ frtab,
                double *__restrict__ epart, double scale)
 {
@@ -340,8 +349,9 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
     const int H = A.H, W = A.W, h = A.h, w = A.w, N = A.N;
     const int R0y = -HLO + Geo<NBY, NBX>::OWNY * wy, R0x = -HLO + Geo<NBY, NBX>::OWNX * wx;
     const int Pb = R0y + 64 * s, Xb = R0x + 64 * u;  // padded coordinates of this block's first row / column (even)
-    float *Rown = lds + wave * RW;
-    const float *Rup = lds + (wave - NBX) * RW, *Rdn = lds + (wave + NBX) * RW, *Rlf = lds + (wave - 1) * RW, *Rrt = lds + (wave + 1) * RW;
+    float *Rown = lds + wave * RW;  // this wave's transpose region
+    float *Xown = lds + L::OFF_SL + wave * XW;
+    const float *Xup = Xown - NBX * XW, *Xdn = Xown + NBX * XW, *Xlf = Xown - XW, *Xrt = Xown + XW;
     float *edge = lds + L::OFF_EDGE;
     int *frt = reinterpret_cast<int *>(lds + L::OFF_FR);
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
@@ -360,22 +370,20 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         quads_load<-1, 16>(a, rs, vq0, W16);
     }
     SRX_PSTAMP(1);
-    blur_block(a, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_A, lane, ld8(A.kby));
+    blur_block(a, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kby));
     SRX_PSTAMP(2);
     edge_replicate(a, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
     float hi[3];
-    prefilter_block(a, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_B, lane, hi);
+    prefilter_block(a, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_B, lane, hi);
     SRX_PSTAMP(3);
-    __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
     float c[64];
     transpose64(a, c, Rown, lane);
     SRX_PSTAMP(4);
     // ================= row layout: lane = row Pb + lane, c[j] = column Xb + j =================
-    blur_block(c, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_A, lane, ld8(A.kbx));
+    blur_block(c, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.kbx));
     SRX_PSTAMP(5);
     edge_replicate(c, Xb, W + SRX_NPAD - 1, R0x + 64 * NBX - 1 > W + SRX_NPAD - 1, edge + 64 * s + lane);
-    prefilter_block(c, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_B, lane, hi);
-    __syncthreads();
+    prefilter_block(c, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_B, lane, hi);
     SRX_PSTAMP(6);
     // ================= pairs of frames =================
     const int Ya = R0y + HLO, Yb = R0y + 64 * NBY - HHI, Xa = R0x + HLO, Xe = R0x + 64 * NBX - HHI;  // owned tap origins
@@ -384,14 +392,42 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
     const __amdgpu_buffer_rsrc_t rs_er = fused::plane_rsrc(err + (size_t)b * N * h * w, (size_t)N * h * w);
     float sq = 0.f;
     for (int kp = 0; 2 * kp < N; kp++) {
+        // ---- this lane in the second half of the step: (frame kk of the pair, LR column jl of the block)
+        const int k = 2 * kp + kk;
+        const bool kok = k < N;
+        const int *fk = frt + (kok ? k : 0) * 20;
+        const int oy = fk[0], ox = fk[1];
+        const int py = (oy + Pb) & 1, px = (ox + Xb) & 1;
+        const int ibase = asr1(Pb + py - oy), jg = asr1(Xb + px - ox) + jl;  // LR row of sim[0], LR column of this lane
+        // owned LR rows of this lane's frame: tap origin Y = Pb + 2 i + py in [Ya, Yb), LR row ibase + i in [0, h)
+        const int X = Xb + 2 * jl + px;
+        const bool lane_ok = kok && X >= Xa && X < Xe && jg >= 0 && jg < w;
+        const int ilo = max(asr1(Ya - Pb - py + 1), -ibase), ihi = min(asr1(Yb - 1 - Pb - py) + 1, h - ibase);
+        const unsigned nrow = lane_ok ? (unsigned)max(ihi - ilo, 0) : 0u;
+        const int vbase = lane_ok ? ((k * h + ibase) * w + jg) * 4 : VOFF_OUT, w4 = w * 4;
+        // owned rows of an interior block: i in [I0, I1) whatever the frame (Ya - Pb and Yb - Pb are even); blocks whose LR rows
+        // may leave the image check every row
+        constexpr int IA0 = HLO / 2, IB1 = 32 * NBY - HHI / 2 - 32 * (NBY - 1);
+        const bool interior = asr1(Pb - A.oyf_max) >= 0 && asr1(Pb + 1 - A.oyf_min) + 32 <= h;
+        const int rowsel = !interior ? 0 : (s == 0 ? 1 : (s == NBY - 1 ? 2 : 3));
+        float lv[32];  // (ONE array for every variant: two would both count as live across the exchange)
+#if SRX_BT_PREFETCH
+        // interior blocks request their LR samples ahead of the H-FIR (the 32 checked rows of an edge block would spill)
+        if (rowsel == 1)
+            fwd_rows_load<IA0, 32, false>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else if (rowsel == 2)
+            fwd_rows_load<0, IB1, false>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else if (NBY > 2 && rowsel == 3)
+            fwd_rows_load<0, (NBY > 2 ? 32 : 0), false>(lv, rs_lr, vbase, w4, ilo, nrow);
+#endif
         float sv[64];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const int k = 2 * kp + half;
+            const int kf = 2 * kp + half;
             float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
             int par = 0;
-            if (k < N) {
-                const BFrame &f = A.fr[k];
+            if (kf < N) {
+                const BFrame &f = A.fr[kf];
                 w0 = f.wxf[0], w1 = f.wxf[1], w2 = f.wxf[2], w3 = f.wxf[3];
                 par = (f.oxf + Xb) & 1;
             }
@@ -411,38 +447,26 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         float t[64];
         transpose64(sv, t, Rown, lane);
         SRX_PSTAMP(8);
-        // ---- lane = (frame kk of the pair, LR column jl of the block), t[y] = row Pb + y
-        const int k = 2 * kp + kk;
-        const bool kok = k < N;
-        const int *fk = frt + (kok ? k : 0) * 20;
-        const int oy = fk[0], ox = fk[1];
-        const int py = (oy + Pb) & 1, px = (ox + Xb) & 1;
-        const int ibase = asr1(Pb + py - oy), jg = asr1(Xb + px - ox) + jl;  // LR row of sim[0], LR column of this lane
-        float wv[5];
+        float wv[5];  // this lane's V-FIR weights, its frame's parity folded in (re-read here: nothing of it lives through the transpose)
         {
-            const float y0 = __int_as_float(fk[4]), y1 = __int_as_float(fk[5]), y2 = __int_as_float(fk[6]), y3 = __int_as_float(fk[7]);
-            wv[0] = py ? 0.f : y0, wv[1] = py ? y0 : y1, wv[2] = py ? y1 : y2, wv[3] = py ? y2 : y3, wv[4] = py ? y3 : 0.f;
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            const int k2 = 2 * kp + ((tl & 63) >> 5);
+            const int *f2 = frt + (k2 < N ? k2 : 0) * 20;
+            const int py2 = (f2[0] + Pb) & 1;
+            const float y0 = __int_as_float(f2[4]), y1 = __int_as_float(f2[5]), y2 = __int_as_float(f2[6]), y3 = __int_as_float(f2[7]);
+            wv[0] = py2 ? 0.f : y0, wv[1] = py2 ? y0 : y1, wv[2] = py2 ? y1 : y2, wv[3] = py2 ? y2 : y3, wv[4] = py2 ? y3 : 0.f;
         }
-        // owned LR rows of this lane's frame: tap origin Y = Pb + 2 i + py in [Ya, Yb), LR row ibase + i in [0, h)
-        const int X = Xb + 2 * jl + px;
-        const bool lane_ok = kok && X >= Xa && X < Xe && jg >= 0 && jg < w;
-        const int ilo = max(asr1(Ya - Pb - py + 1), -ibase), ihi = min(asr1(Yb - 1 - Pb - py) + 1, h - ibase);
-        const unsigned nrow = lane_ok ? (unsigned)max(ihi - ilo, 0) : 0u;
-        const int vbase = lane_ok ? ((k * h + ibase) * w + jg) * 4 : VOFF_OUT, w4 = w * 4;
-        // owned rows of an interior block: i in [I0, I1) whatever the frame (Ya - Pb and Yb - Pb are even); blocks whose LR rows
-        // may leave the image check every row
-        constexpr int IA0 = HLO / 2, IB1 = 32 * NBY - HHI / 2 - 32 * (NBY - 1);
-        const bool interior = asr1(Pb - A.oyf_max) >= 0 && asr1(Pb + 1 - A.oyf_min) + 32 <= h;
-        const int rowsel = !interior ? 0 : (s == 0 ? 1 : (s == NBY - 1 ? 2 : 3));
-        float lv[32];
         if (rowsel == 0)
             fwd_rows_load<0, 32, true>(lv, rs_lr, vbase, w4, ilo, nrow);
+#if !SRX_BT_PREFETCH
         else if (rowsel == 1)
             fwd_rows_load<IA0, 32, false>(lv, rs_lr, vbase, w4, ilo, nrow);
         else if (rowsel == 2)
             fwd_rows_load<0, IB1, false>(lv, rs_lr, vbase, w4, ilo, nrow);
-        else
-            fwd_rows_load<0, 32, false>(lv, rs_lr, vbase, w4, ilo, nrow);
+        else if (NBY > 2 && rowsel == 3)
+            fwd_rows_load<0, (NBY > 2 ? 32 : 0), false>(lv, rs_lr, vbase, w4, ilo, nrow);
+#endif
         // the three rows past the block: the block below holds them
         float *ex = lds + L::OFF_EX + wave * 512 + (kp & 1) * 256;
         const float *exd = lds + L::OFF_EX + (wave + NBX) * 512 + (kp & 1) * 256;
@@ -452,14 +476,16 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         float th[3] = {0.f, 0.f, 0.f};
         if (s < NBY - 1)
             th[0] = exd[lane], th[1] = exd[64 + lane], th[2] = exd[128 + lane];
+        float sqp = 0.f;  // this pair's share of the sum (a lane that owns no LR column read zeros for lr: its residuals do not count)
         if (rowsel == 0)
-            fwd_rows<0, 32, true>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+            fwd_rows<0, 32, true>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sqp);
         else if (rowsel == 1)
-            fwd_rows<IA0, 32, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+            fwd_rows<IA0, 32, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sqp);
         else if (rowsel == 2)
-            fwd_rows<0, IB1, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
-        else
-            fwd_rows<0, 32, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sq);
+            fwd_rows<0, IB1, false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sqp);
+        else if (NBY > 2)
+            fwd_rows<0, (NBY > 2 ? 32 : 0), false>(t, th, wv, lv, rs_er, vbase, w4, ilo, nrow, sqp);
+        sq += vbase != VOFF_OUT ? sqp : 0.f;
     }
     SRX_PSTAMP(10);
     if (epart) {
@@ -482,7 +508,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
 // grid (nwx, nwy, B).  The window (0, 0) of an item also sums the forward kernel's per-window MSE partials.
 // =========================================================================================================================
 template <int NBY, int NBX>
-__global__ void __launch_bounds__(NBY *NBX * 64)
+__global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bbwd(const float *__restrict__ err, float *__restrict__ S, BArgs A, const int *__restrict__ frtab, const double *__restrict__ epart,
                double *__restrict__ errors, int errors_stride)
 {
@@ -495,8 +521,9 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
     const int H = A.H, W = A.W, h = A.h, w = A.w, N = A.N;
     const int R0y = -HLO + Geo<NBY, NBX>::OWNY * wy, R0x = -HLO + Geo<NBY, NBX>::OWNX * wx;
     const int Pb = R0y + 64 * s, Xb = R0x + 64 * u;
-    float *Rown = lds + wave * RW;
-    const float *Rup = lds + (wave - NBX) * RW, *Rdn = lds + (wave + NBX) * RW, *Rlf = lds + (wave - 1) * RW, *Rrt = lds + (wave + 1) * RW;
+    float *Rown = lds + wave * RW;  // this wave's transpose region
+    float *Xown = lds + L::OFF_SL + wave * XW;
+    const float *Xup = Xown - NBX * XW, *Xdn = Xown + NBX * XW, *Xlf = Xown - XW, *Xrt = Xown + XW;
     int *frt = reinterpret_cast<int *>(lds + L::OFF_FR);
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
     for (int i = tid; i < N * 20; i += L::NT)
@@ -527,6 +554,29 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
 #pragma unroll
     for (int x = 0; x < 64; x++)
         v[x] = 0.f;
+    // the residual rows of a pair: requested one pair ahead (E is free once the V-FIR' has run; the transpose and the H-FIR' of
+    // this pair cover the latency of the next pair's loads)
+    float E[34];
+    const int w4 = w * 4;
+    const bool lo_ok = asr1(Pb + A.oyb_min - SRX_NPAD) >= 0, hi_ok = asr1(Pb + A.oyb_max + 1 - SRX_NPAD) + 34 <= h;
+    auto request = [&](int kp) {
+        const int k = 2 * kp + kk;
+        const bool kok = k < N;
+        const int *fk = frt + (kok ? k : 0) * 20;
+        const int oy = fk[2], ox = fk[3];
+        const int py = (oy + Pb) & 1, px = (ox + Xb) & 1;
+        const int ibase = asr1(Pb + oy + py - SRX_NPAD), jg = asr1(Xb + ox + px - SRX_NPAD) + jl;
+        const int jc = min(max(jg, 0), w - 1);  // the left pad repeats LR column 0
+        const int vrow0 = ((kok ? k : 0) * h * w + jc) * 4;
+        // the top pad repeats LR row 0 (first window row); rows past the last are zeros (last window rows)
+        if (lo_ok && hi_ok)
+            bwd_rows_load<false, false>(E, rs_er, vrow0, ibase, w4, h);
+        else if (hi_ok)
+            bwd_rows_load<true, false>(E, rs_er, vrow0, ibase, w4, h);
+        else
+            bwd_rows_load<true, true>(E, rs_er, vrow0, ibase, w4, h);
+    };
+    request(0);
     for (int kp = 0; 2 * kp < N; kp++) {
         // ---- lane = (frame kk of the pair, LR column), registers = LR rows, then HR rows
         float uu[64];
@@ -536,19 +586,8 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
             const int *fk = frt + (kok ? k : 0) * 20;
             const int oy = fk[2], ox = fk[3];
             const int py = (oy + Pb) & 1, px = (ox + Xb) & 1;
-            const int ibase = asr1(Pb + oy + py - SRX_NPAD), jg = asr1(Xb + ox + px - SRX_NPAD) + jl;
+            const int jg = asr1(Xb + ox + px - SRX_NPAD) + jl;
             const bool lane_ok = kok && jg < w;  // (a lane past the last LR column, a frame past the last: zero weights)
-            const int jc = min(max(jg, 0), w - 1);  // the left pad repeats LR column 0
-            const int w4 = w * 4, vrow0 = ((kok ? k : 0) * h * w + jc) * 4;
-            float E[34];
-            // the top pad repeats LR row 0 (first window row); rows past the last are zeros (last window rows)
-            const bool lo_ok = asr1(Pb + A.oyb_min - SRX_NPAD) >= 0, hi_ok = asr1(Pb + A.oyb_max + 1 - SRX_NPAD) + 34 <= h;
-            if (lo_ok && hi_ok)
-                bwd_rows_load<false, false>(E, rs_er, vrow0, ibase, w4, h);
-            else if (hi_ok)
-                bwd_rows_load<true, false>(E, rs_er, vrow0, ibase, w4, h);
-            else
-                bwd_rows_load<true, true>(E, rs_er, vrow0, ibase, w4, h);
             const float y0 = lane_ok ? __int_as_float(fk[12]) : 0.f, y1 = lane_ok ? __int_as_float(fk[13]) : 0.f,
                         y2 = lane_ok ? __int_as_float(fk[14]) : 0.f, y3 = lane_ok ? __int_as_float(fk[15]) : 0.f;
             const float a0 = py ? y1 : y0, a1 = py ? y3 : y2;
@@ -572,6 +611,8 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
                 }
             }
         }
+        if (2 * (kp + 1) < N)
+            request(kp + 1);
         SRX_PSTAMP(13);
         float g[64];
         transpose64(uu, g, Rown, lane);
@@ -621,13 +662,11 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         }
     }
     SRX_PSTAMP(16);
-    __syncthreads();  // the exchange buffers and the slots are free
     float hi[3];
-    prefilter_block(v, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_B, lane, hi);
+    prefilter_block(v, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_B, lane, hi);
     SRX_PSTAMP(17);
     zero_outside(v, Xb, W + SRX_NPAD - 1);
-    blur_block(v, u == 0, u == NBX - 1, Rown, Rlf, Rrt, SLOT_A, lane, ld8(A.ktx));
-    __syncthreads();
+    blur_block(v, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.ktx));
     SRX_PSTAMP(18);
     float r[64];
     transpose64(v, r, Rown, lane);
@@ -649,10 +688,10 @@ __global__ void __launch_bounds__(NBY *NBX * 64)
         quads_load<-1, QB>(hv, rs_s, vq0, W16);
     else
         quads_load<-1, 16>(hv, rs_s, vq0, W16);
-    prefilter_block(r, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_B, lane, hi);
+    prefilter_block(r, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_B, lane, hi);
     SRX_PSTAMP(20);
     zero_outside(r, Pb, H + SRX_NPAD - 1);
-    blur_block(r, s == 0, s == NBY - 1, Rown, Rup, Rdn, SLOT_A, lane, ld8(A.kty));
+    blur_block(r, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kty));
     SRX_PSTAMP(21);
     {
         const float sn = A.sn;
@@ -688,10 +727,17 @@ static inline size_t ws_bytes(int B, int N, int h, int w, int H, int W)
            align_up(MAXF * 20 * sizeof(int));
 }
 
-static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
-               int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
+// Window shape: 2 x 2 waves (128 x 128 padded coordinates, 96 x 96 owned: 1.78x recompute), two or three workgroups per CU.  Measured
+// against 2 x 4 (128 x 256, 96 x 224 owned, 1.52x recompute, ONE workgroup of eight waves per CU) on 1536 x 2048: one frame 48.3
+// against 44.4 us per iteration, eight frames 211 against 185 -- eight waves that meet at every barrier wait for their slowest,
+// two independent workgroups fill each other's waits (srx_ztile.hpp found the same).  The shape is fixed, so a batch gives every
+// item the bits it gets alone.
+static inline bool wide_windows(int W) { (void)W; return false; }
+
+template <int NBY, int NBX>
+static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
+                 int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
 {
-    constexpr int NBY = 2, NBX = 2;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
     BArgs A;
     A.N = N, A.h = h, A.w = w, A.H = H, A.W = W;
@@ -755,6 +801,14 @@ static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, co
     hipLaunchKernelGGL(k_btile_copy_out, cgrid, dim3(256), 0, st, S, H, W, H4, hr);
     SRX_CHECK_LAUNCH();
     return SRX_OK;
+}
+
+static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
+               int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
+{
+    if (wide_windows(W))
+        return ibp_t<2, 4>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
+    return ibp_t<2, 2>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
 }
 
 }  // namespace btile

@@ -358,7 +358,8 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "composed"
     close(hr_c[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     hr_p, errs_p = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_PER_FRAME)
-    assert S.last_path() == "fused"
+    # (x2, float32, rank-1 PSF: the per-frame formulation runs on register-resident windows, srx_btile.hpp)
+    assert S.last_path() == ("btile" if prec == "f32" and f == 2 and psf_name == "gauss" else "fused")
     close(hr_p[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     np.testing.assert_allclose(errs_p[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
 
@@ -820,6 +821,107 @@ def test_full_size_x4_frame_paths_agree():
     assert float((hr_w - hr_d).abs().max()) < 5e-4  # the two window shapes agree to the warm-up truncation
     hr2w, e2w = S.ibp_batched(two_lr, shifts, psf, two_saa, f, 6, 0.5, flags=S.FLAG_DIAG_WIDE_WINDOWS)
     assert torch.equal(hr2w[0], hr_w[0]) and torch.equal(e2w[0], e_w[0])
+
+
+BTILE_CFGS = {
+    # name: (shifts (LR px), (h, w) LR)
+    "meas4": (synth.MEASURED_4, (150, 277)),   # the reference's rgb_cal_target shifts: 4 x 6 windows, ragged last windows
+    "five_wide": ([(0.3, -1.2), (1.7, 0.45), (-1.9, 1.99), (0.0, 0.25), (-0.6, -0.6)], (70, 83)),  # odd N (a half-empty pair), |2 s| up to 4, an integer one
+    "tiny": (synth.MEASURED_4, (20, 33)),      # one window; the image ends inside its first block row
+    "smallest": (synth.MEASURED_4, (16, 16)),  # 32 x 32 HR, the smallest frame the kernels take
+    "two_frames": ([(0.37, -0.21), (-0.12, 0.45)], (64, 96)),  # one pair
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(BTILE_CFGS))
+def test_frame_shift_kernel_vs_oracle(cfg):
+    """k_ibp_bfwd / k_ibp_bbwd (per-frame fractional shifts at x2, the reference's rgb_cal_target, on register-resident windows)
+    against the oracle after 1, 2 and 6 iterations (state and MSE trace), against the tile kernels they replace, in place, as a
+    batch, and run to run."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    shifts, (h, w) = BTILE_CFGS[cfg]
+    f, psf = 2, synth.gaussian_psf()
+    O.set_threads(16)
+    try:
+        lrs, saas = [], []
+        for i in range(2):
+            truth = synth.truth_image(h * f, w * f, seed=800 + i)
+            lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=900 + i)
+            lrs.append(lr), saas.append(O.shift_and_add(list(lr), shifts, f))
+        lr, saa = np.stack(lrs), np.stack(saas)
+        for n in (1, 2, 6):
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5)
+            assert S.last_path() == "btile"
+            for i in range(2 if n == 6 else 1):
+                hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
+                close(hr[i].cpu().numpy(), hr_o, IBP_TOL["f32"])
+                np.testing.assert_allclose(errs[i].cpu().numpy(), err_o, rtol=ERR_RTOL["f32"])
+    finally:
+        O.set_threads(1)
+    hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "fused"
+    assert float((hr - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    buf = torch.from_numpy(saa).cuda().float()
+    hr2, errs2 = S.ibp_batched(lr, shifts, psf, buf, f, 6, 0.5, out=buf)
+    assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
+    one, e1 = S.ibp_batched(lr[1:2], shifts, psf, saa[1:2], f, 6, 0.5)
+    assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
+
+
+def test_frame_shift_kernel_80_iterations():
+    """The reference's rgb_cal_target defaults (four measured shifts, Gaussian PSF; rgb_cal_target/run_sr.py:171-192, 340-373) for its 50
+    and for 80 iterations on a frame of several windows, against the oracle at the north-star tolerances."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, psf, (h, w) = 2, synth.MEASURED_4, synth.gaussian_psf(), (110, 150)
+    O.set_threads(16)
+    try:
+        truth = synth.truth_image(h * f, w * f, seed=81)
+        lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=82)
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        refs = {n: O.ibp(list(lr), shifts, psf, saa_o, f, n, 0.5) for n in (50, 80)}
+    finally:
+        O.set_threads(1)
+    for n, (hr_o, err_o) in refs.items():
+        hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, n, 0.5, verbose=False)
+        assert S.last_path() == "btile"
+        close(hr, hr_o, IBP_TOL["f32"])
+        np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL["f32"])
+        assert synth.psnr(hr, hr_o) > 90.0 and abs(synth.psnr(hr, truth) - synth.psnr(hr_o, truth)) < 0.01
+        u8_close(hr, hr_o)
+
+
+def test_full_size_rgb_frame_paths_agree():
+    """The reference's rgb_cal_target shape at full size (768 x 1024 -> 1536 x 2048, N = 4 measured shifts): the window kernels and the
+    tile kernels agree, noise-free frames of x keep x, repeated calls are bit-identical, and a batch equals its items."""
+    S.set_precision("f32")
+    f, shifts, psf = 2, synth.MEASURED_4, synth.gaussian_psf()
+    x = torch.from_numpy(synth.truth_image(384, 512, seed=26)).cuda().float().repeat(4, 4)[None].contiguous()
+    lr = torch.stack([S.forward_model_batched(x, psf, s, f) for s in shifts], dim=1).contiguous()
+    assert lr.shape == (1, 4, 768, 1024)
+    hr, errs = S.ibp_batched(lr, shifts, psf, x, f, 3, 0.5)
+    assert S.last_path() == "btile"
+    assert float((hr - x).abs().max()) < 2e-3 and float(errs.max()) < 1e-6
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    lrn = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255)
+    saa = S.shift_and_add_batched(lrn, shifts, f)
+    hr_d, e_d = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5)
+    assert S.last_path() == "btile"
+    hr_t, e_t = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "fused"
+    assert float((hr_d - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(e_d.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    assert float(e_d[0, -1]) < float(e_d[0, 0])
+    for _ in range(3):
+        hr_r, e_r = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5)
+        assert torch.equal(hr_r, hr_d) and torch.equal(e_r, e_d)
+    two_lr = torch.cat([lrn, torch.flip(lrn, dims=(2,))])
+    two_saa = S.shift_and_add_batched(two_lr, shifts, f)
+    hr2, e2 = S.ibp_batched(two_lr, shifts, psf, two_saa, f, 6, 0.5)
+    assert torch.equal(hr2[0], hr_d[0]) and torch.equal(e2[0], e_d[0])
 
 
 # ---------------------------------------------------------------------------------------------------------
