@@ -150,14 +150,62 @@ __device__ __forceinline__ void zero_outside(float (&a)[64], int c0, int hi)
     }
 }
 
-// 7-tap correlation along the registers with three samples from either neighbour block (srx_patch.hpp's blur_block with the weights
-// as an argument array)
-using patch::blur_block;
+// 7-tap correlation along the registers with three samples from either neighbour block: srx_patch.hpp's blur_block with TWO adjacent
+// outputs per instruction (v_pk_fma_f32).  These kernels run one or two waves per SIMD, where a wave issues an instruction every
+// ~5 cycles whatever it does (profiles/README.md): what counts is the number of instructions, and a packed fma is one.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef SRX_BT_PK
+#define SRX_BT_PK 1
+#endif
+__device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last, float *Xown, const float *Xprev, const float *Xnext, int s6, int lane,
+                                           const f8 kb)
+{
+#if !SRX_BT_PK
+    patch::blur_block(a, first, last, Xown, Xprev, Xnext, s6, lane, kb);
+#else
+    Xown[s6 + lane] = a[0];
+    Xown[s6 + 64 + lane] = a[1];
+    Xown[s6 + 128 + lane] = a[2];
+    Xown[s6 + 192 + lane] = a[61];
+    Xown[s6 + 256 + lane] = a[62];
+    Xown[s6 + 320 + lane] = a[63];
+    __syncthreads();
+    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+    if (!first)
+        hl[0] = Xprev[s6 + 192 + lane], hl[1] = Xprev[s6 + 256 + lane], hl[2] = Xprev[s6 + 320 + lane];
+    if (!last)
+        hr[0] = Xnext[s6 + lane], hr[1] = Xnext[s6 + 64 + lane], hr[2] = Xnext[s6 + 128 + lane];
+    float c0 = hl[0], c1 = hl[1], c2 = hl[2];
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+        float w[14];
+        w[0] = c0, w[1] = c1, w[2] = c2;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            w[3 + j] = a[j0 + j];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            w[11 + j] = j0 + 8 + j < 64 ? a[j0 + 8 + j] : hr[j];
+        c0 = w[8], c1 = w[9], c2 = w[10];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            v2f acc = (v2f){kb[0], kb[0]} * (v2f){w[j], w[j + 1]};
+#pragma unroll
+            for (int k = 1; k < 7; k++)
+                acc = __builtin_elementwise_fma((v2f){kb[k], kb[k]}, (v2f){w[j + k], w[j + k + 1]}, acc);
+            a[j0 + j] = acc.x, a[j0 + j + 1] = acc.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+}
 
 // H-FIR of frame HALF of a pair with decimation: s[32 HALF + j] = sum_b w[b] c[2 j + PAR + b]
 template <int PAR, int HALF>
 __device__ __forceinline__ void hfir_dec(const float (&c)[64], const float (&hi)[3], float w0, float w1, float w2, float w3, float (&s)[64])
 {
+    asm volatile("; H-FIR, parity %0" ::"n"(PAR));  // (keeps the caller's wave-uniform parity branch a branch: if-converted, every operand
+                                                    // of both variants went through a v_cndmask, 70 more instructions per frame)
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         auto C = [&](int i) -> float { return i < 64 ? c[i < 64 ? i : 0] : hi[i < 64 ? 0 : i - 64]; };
@@ -170,6 +218,7 @@ __device__ __forceinline__ void hfir_dec(const float (&c)[64], const float (&hi)
 template <int PAR, int HALF>
 __device__ __forceinline__ void hfir_up(float (&A)[64], const float (&g)[64], const float (&gh)[2], float w0, float w1, float w2, float w3)
 {
+    asm volatile("; H-FIR', parity %0" ::"n"(PAR));  // (as in hfir_dec)
 #pragma unroll
     for (int t = 0; t < 32; t++) {
         auto G = [&](int i) -> float { return i < 32 ? g[32 * HALF + (i < 32 ? i : 0)] : gh[i < 32 ? 0 : i - 32]; };
@@ -592,11 +641,22 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
                         y2 = lane_ok ? __int_as_float(fk[14]) : 0.f, y3 = lane_ok ? __int_as_float(fk[15]) : 0.f;
             const float a0 = py ? y1 : y0, a1 = py ? y3 : y2;
             const float b0 = py ? y0 : 0.f, b1 = py ? y2 : y1, b2 = py ? 0.f : y3;
+#if SRX_BT_PK
+            const v2f w0 = {a0, b0}, w1 = {a1, b1}, w2 = {0.f, b2};  // both rows of a pair from one residual row per instruction
+#pragma unroll
+            for (int t = 0; t < 32; t++) {
+                v2f acc = w2 * (v2f){E[t + 2], E[t + 2]};
+                acc = __builtin_elementwise_fma(w1, (v2f){E[t + 1], E[t + 1]}, acc);
+                acc = __builtin_elementwise_fma(w0, (v2f){E[t], E[t]}, acc);
+                uu[2 * t] = acc.x, uu[2 * t + 1] = acc.y;
+            }
+#else
 #pragma unroll
             for (int t = 0; t < 32; t++) {
                 uu[2 * t] = fmaf(a0, E[t], a1 * E[t + 1]);
                 uu[2 * t + 1] = fmaf(b0, E[t], fmaf(b1, E[t + 1], b2 * E[t + 2]));
             }
+#endif
             if (Pb < SRX_NPAD + 5) {  // top pad: the odd pad samples also hold LR row 0 (E[0]: ibase <= 0 here)
                 const float wq[4] = {y0, y1, y2, y3};
 #pragma unroll
@@ -732,8 +792,6 @@ static inline size_t ws_bytes(int B, int N, int h, int w, int H, int W)
 // against 44.4 us per iteration, eight frames 211 against 185 -- eight waves that meet at every barrier wait for their slowest,
 // two independent workgroups fill each other's waits (srx_ztile.hpp found the same).  The shape is fixed, so a batch gives every
 // item the bits it gets alone.
-static inline bool wide_windows(int W) { (void)W; return false; }
-
 template <int NBY, int NBX>
 static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
                  int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
@@ -806,8 +864,6 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
 static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
                int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
 {
-    if (wide_windows(W))
-        return ibp_t<2, 4>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
     return ibp_t<2, 2>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
 }
 

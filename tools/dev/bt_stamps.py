@@ -28,5 +28,13 @@ for seq, nm in (([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10], "k_ibp_bfwd"), ([12, 13, 14
     for a, b in zip(seq, seq[1:]):
         d = t[b] - t[a]
         print(f"   {names[b]:38s} median {np.median(d):8.0f}  p90 {np.percentile(d,90):8.0f}")
+    T, F = t.max(axis=2), t.min(axis=2)
+    print("   critical path (last wave to last wave; spread = last - first wave at the phase's end), median over windows:")
+    for a, b in zip(seq, seq[1:]):
+        print(f"   {names[b]:38s} {np.median(T[b] - T[a]):8.0f}   spread {np.median(T[b] - F[b]):7.0f}")
+    print(f"   total {np.median(T[seq[-1]] - F[seq[0]]):.0f}; first-wave start to last-wave start {np.median(T[seq[0]] - F[seq[0]]):.0f}")
+    for st in (seq[0], seq[len(seq) // 2], seq[-1]):
+        rel = t[st] - t[st].min(axis=1, keepdims=True)
+        print(f"   stamp {st}: median arrival of waves 0..3 after the window's first wave: {np.median(rel, axis=0).round(0)}")
     start = t[seq[0]]
     print("   window start spread (first..last wave start over all windows):", int(start.max() - start.min()), " end spread:", int(t[seq[-1]].max() - t[seq[-1]].min()), " whole kernel:", int(t[seq[-1]].max() - start.min()))
