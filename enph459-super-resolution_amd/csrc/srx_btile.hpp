@@ -33,12 +33,14 @@ using patch::FIX;
 using patch::K2;
 using patch::PZ;
 using patch::RW;
-using patch::transpose64;
 using patch::ZP;
 
 #ifndef SRX_BT_PREFETCH
 #define SRX_BT_PREFETCH 1  // the forward kernel's LR samples requested ahead of the H-FIR and the transpose
 #endif
+#ifndef SRX_BT_DBG
+#define SRX_BT_DBG 0  // timing ablations of a development build (results are wrong): 1 no residual stores, 2 no state stores, 4 no LR loads,
+#endif                // 8 no residual loads, 16 no state loads, 32 no transposes (registers copied)
 #ifndef SRX_BT_MINB
 #define SRX_BT_MINB 2  // workgroups per CU the register allocation aims at
 #endif
@@ -175,26 +177,34 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
         hl[0] = Xprev[s6 + 192 + lane], hl[1] = Xprev[s6 + 256 + lane], hl[2] = Xprev[s6 + 320 + lane];
     if (!last)
         hr[0] = Xnext[s6 + lane], hr[1] = Xnext[s6 + 64 + lane], hr[2] = Xnext[s6 + 128 + lane];
+    // In place, 16 outputs = 8 packed accumulators at a time, tap-major: eight independent instructions between two that depend on each
+    // other (a dependent VALU instruction issues ~11 cycles behind its producer, and with one or two waves per SIMD nobody fills the gap:
+    // four accumulators per group ran the blur at the latency of its 7-deep chains).
+    constexpr int G = 16;
     float c0 = hl[0], c1 = hl[1], c2 = hl[2];
 #pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {
-        float w[14];
+    for (int j0 = 0; j0 < 64; j0 += G) {
+        float w[G + 6];
         w[0] = c0, w[1] = c1, w[2] = c2;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < G; j++)
             w[3 + j] = a[j0 + j];
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            w[11 + j] = j0 + 8 + j < 64 ? a[j0 + 8 + j] : hr[j];
-        c0 = w[8], c1 = w[9], c2 = w[10];
+            w[G + 3 + j] = j0 + G + j < 64 ? a[j0 + G + j] : hr[j];
+        c0 = w[G], c1 = w[G + 1], c2 = w[G + 2];
+        v2f acc[G / 2];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            v2f acc = (v2f){kb[0], kb[0]} * (v2f){w[j], w[j + 1]};
+        for (int q = 0; q < G / 2; q++)
+            acc[q] = (v2f){kb[0], kb[0]} * (v2f){w[2 * q], w[2 * q + 1]};
 #pragma unroll
-            for (int k = 1; k < 7; k++)
-                acc = __builtin_elementwise_fma((v2f){kb[k], kb[k]}, (v2f){w[j + k], w[j + k + 1]}, acc);
-            a[j0 + j] = acc.x, a[j0 + j + 1] = acc.y;
-        }
+        for (int k = 1; k < 7; k++)
+#pragma unroll
+            for (int q = 0; q < G / 2; q++)
+                acc[q] = __builtin_elementwise_fma((v2f){kb[k], kb[k]}, (v2f){w[2 * q + k], w[2 * q + k + 1]}, acc[q]);
+#pragma unroll
+        for (int q = 0; q < G / 2; q++)
+            a[j0 + 2 * q] = acc[q].x, a[j0 + 2 * q + 1] = acc[q].y;
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
@@ -234,6 +244,17 @@ __device__ __forceinline__ void hfir_up(float (&A)[64], const float (&g)[64], co
 
 __device__ __forceinline__ int asr1(int x) { return x >> 1; }  // floor(x / 2)
 
+__device__ __forceinline__ void transpose64(const float (&a)[64], float (&r)[64], float *Tw, int lane)
+{
+#if SRX_BT_DBG & 32
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+        r[i] = a[i];
+#else
+    patch::transpose64(a, r, Tw, lane);
+#endif
+}
+
 constexpr int VOFF_OUT = (int)0x80000000;  // a lane offset that stays out of every descriptor's range when a row offset (< 2^30) is added
 
 // LR rows [I0, I1) of the forward pair step: sim = V-FIR of t with this lane's five weights, err = lr - sim (stored), sq += err^2.
@@ -247,7 +268,7 @@ __device__ __forceinline__ void fwd_rows_load(float (&lv)[LVN], __amdgpu_buffer_
         int voff = vbase + i * w4;
         if (CHK)
             voff = (unsigned)(i - ilo) < nrow ? voff : VOFF_OUT;
-        lv[i - I0] = fused::buf_load<float>(rs_lr, voff, 0);
+        lv[i - I0] = (SRX_BT_DBG & 4) ? __int_as_float(voff) : fused::buf_load<float>(rs_lr, voff, 0);
     }
 }
 template <int I0, int I1, bool CHK, int LVN>
@@ -268,7 +289,8 @@ __device__ __forceinline__ void fwd_rows(const float (&t)[64], const float (&th)
             voff = ok ? voff : VOFF_OUT;
             e = ok ? e : 0.f;
         }
-        fused::buf_store<float>(e, rs_er, voff, 0);  // out of the descriptor's range: dropped
+        if (!(SRX_BT_DBG & 1))
+            fused::buf_store<float>(e, rs_er, voff, 0);  // out of the descriptor's range: dropped
         sq = fmaf(e, e, sq);
     }
 }
@@ -284,7 +306,7 @@ __device__ __forceinline__ void bwd_rows_load(float (&E)[34], __amdgpu_buffer_rs
         int voff = vrow0 + (CLAMP_LO ? max(row, 0) : row) * w4;
         if (CHECK_HI)
             voff = row < h ? voff : VOFF_OUT;
-        E[m] = fused::buf_load<float>(rs_er, voff, 0);
+        E[m] = (SRX_BT_DBG & 8) ? __int_as_float(voff & 0xffff) : fused::buf_load<float>(rs_er, voff, 0);
     }
 }
 
@@ -298,7 +320,12 @@ using patch::u32x4;
 // quad q of the block (q = -1: the half quad of y = 0, 1; 0..14: y = 2 + 4 q ..; 15: the half quad of y = 62, 63)
 template <int Q> __device__ __forceinline__ void quad_load(float (&a)[64], __amdgpu_buffer_rsrc_t rs, int vq0, int W16)
 {
-    if (Q == -1) {
+    if (SRX_BT_DBG & 16) {
+        if (Q >= 0 && Q < 15)
+            a[2 + 4 * Q] = a[3 + 4 * Q] = a[4 + 4 * Q] = a[5 + 4 * Q] = __int_as_float((vq0 + Q) & 0xffff);
+        else
+            a[Q < 0 ? 0 : 62] = a[Q < 0 ? 1 : 63] = 1.f;
+    } else if (Q == -1) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vq0 - W16 + 8, 0, 0);
         a[0] = __uint_as_float(v.x), a[1] = __uint_as_float(v.y);
     } else if (Q == 15) {
@@ -321,7 +348,10 @@ template <int Q> __device__ __forceinline__ void quad_update(const float (&r)[64
                                                             int ymax)
 {
     auto U = [&](int y) -> float { return y < ymax ? __builtin_amdgcn_fmed3f(fmaf(r[y], sn, hv[y]), 0.f, 255.f) : 0.f; };
-    if (Q == -1) {
+    if (SRX_BT_DBG & 2) {
+        if (U(2 + 4 * (Q < 0 ? 0 : (Q > 14 ? 14 : Q))) == 123.456f)
+            __builtin_amdgcn_raw_buffer_store_b32(1u, rs, vq0, 0, 0);
+    } else if (Q == -1) {
         const u32x2 v = {__float_as_uint(U(0)), __float_as_uint(U(1))};
         __builtin_amdgcn_raw_buffer_store_b64(v, rs, vq0 - W16 + 8, 0, 0);
     } else if (Q == 15) {
