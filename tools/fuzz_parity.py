@@ -18,7 +18,7 @@ from oracle import sr_oracle as O  # noqa: E402
 
 def random_case(rng):
     f = int(rng.choice([2, 2, 3, 4, 4]))
-    kind = rng.choice(["phase", "lattice", "free", "far", "patch", "frame0"], p=[0.25, 0.25, 0.2, 0.1, 0.1, 0.1])
+    kind = rng.choice(["phase", "lattice", "free", "far", "patch", "frame0", "shifted"], p=[0.22, 0.22, 0.16, 0.1, 0.1, 0.1, 0.1])
     N = int(rng.integers(1, 7))
     if kind == "patch":      # k_ibp_patch's domain: a 256 x 256 HR patch, Gaussian PSF, a subset of a phase grid with delta = 1/2
         f = int(rng.choice([2, 4]))
@@ -26,6 +26,12 @@ def random_case(rng):
         N = int(rng.integers(2, len(grid) + 1))
         idx = rng.choice(len(grid), size=N, replace=False)
         return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], 256 // f, 256 // f, synth.gaussian_psf(), int(rng.integers(1, 6)), kind
+    if kind == "shifted":    # k_ibp_bfwd / k_ibp_bbwd's domain: x2, per-frame fractions, |2 s| <= 4, Gaussian PSF, frames of one to several windows
+        N = int(rng.integers(2, 9))
+        shifts = [(float(rng.uniform(-1.99, 1.99)), float(rng.uniform(-1.99, 1.99))) for _ in range(N)]
+        if rng.uniform() < 0.3:  # some frames on integer or half-pixel positions among them
+            shifts[0] = (float(rng.integers(-3, 4)) / 2, float(rng.integers(-3, 4)) / 2)
+        return 2, shifts, int(rng.integers(16, 180)), int(rng.integers(16, 220)), synth.gaussian_psf(), int(rng.integers(1, 6)), kind
     if kind == "frame0":     # k_ibp_ztile's domain: delta = 0 (integer HR shifts), at least 128 x 128 HR pixels, Gaussian PSF
         f = int(rng.choice([2, 3, 4]))
         lo = -min(3, f - 1)

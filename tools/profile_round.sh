@@ -10,7 +10,7 @@
 # The program after "--" is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
 set -e
 TAG=${1:-r03}
-WLS=${2:-"c2 c3_mono c3_mono_measured c3_mono@f64 c3_f4 c3_rgb"}   # name[@precision]
+WLS=${2:-"c2 c3_mono c3_mono_measured c3_mono@f64 c3_f4 c3_rgb c3_rgb_measured"}   # name[@precision]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
