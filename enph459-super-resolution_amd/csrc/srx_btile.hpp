@@ -44,7 +44,8 @@ using patch::ZP;
 #ifndef SRX_BT_MINB
 #define SRX_BT_MINB 2  // workgroups per CU the register allocation aims at
 #endif
-constexpr int HLO = 14, HHI = 18;  // halo before / after the owned span
+constexpr int HLO = 14, HHI = 18;  // halo before / after the owned span (forward kernel: 3 blur + 11 | 3 FIR reach + 11 + 3 + 1)
+constexpr int HHB = 14;            // ... after the owned span of the backward kernel (11 + 3): its windows own 100 x 100, a tenth fewer of them
 constexpr int MAXF = 16;           // frames per call
 constexpr int SLOT_A = 0, SLOT_B = 384, XW = 640;  // a wave's exchange slots: blur (6 x 64 words), prefilter (4 x 64)
 
@@ -408,7 +409,9 @@ __global__ void k_btile_params(BArgs A, int *__restrict__ dst)
 // window geometry shared by the two kernels
 template <int NBY, int NBX> struct Geo {
     static_assert(NBY >= 2 && NBX >= 2, "the first and the last block of a line are different blocks");
-    static constexpr int OWNY = 64 * NBY - HLO - HHI, OWNX = 64 * NBX - HLO - HHI;
+    static constexpr int OWNY = 64 * NBY - HLO - HHI, OWNX = 64 * NBX - HLO - HHI;      // forward
+    static constexpr int OWBY = 64 * NBY - HLO - HHB, OWBX = 64 * NBX - HLO - HHB;      // backward
+    static_assert(OWNY % 4 == 0 && OWBY % 4 == 0, "owned spans start at whole row quads of the state plane");
 };
 
 // =========================================================================================================================
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     int wx, wy, b;
     xcd_block(wx, wy, b);
     const int H = A.H, W = A.W, h = A.h, w = A.w, N = A.N;
-    const int R0y = -HLO + Geo<NBY, NBX>::OWNY * wy, R0x = -HLO + Geo<NBY, NBX>::OWNX * wx;
+    const int R0y = -HLO + Geo<NBY, NBX>::OWBY * wy, R0x = -HLO + Geo<NBY, NBX>::OWBX * wx;
     const int Pb = R0y + 64 * s, Xb = R0x + 64 * u;
     float *Rown = lds + wave * RW;  // this wave's transpose region
     float *Xown = lds + L::OFF_SL + wave * XW;
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
         frt[i] = frtab[i];
     __syncthreads();
     if (errors && wx == 0 && wy == 0) {  // MSE trace of this iteration: the forward windows' sums in a fixed order
-        const int nwin = A.nwx * A.nwy;
+        const int nwin = A.nwx * A.nwy;  // (the FORWARD kernel's windows)
         const double *p = epart + (size_t)b * nwin;
         double acc = 0.0;
         for (int i = tid; i < nwin; i += L::NT)
@@ -763,14 +766,14 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     SRX_PSTAMP(19);
     // ================= column layout: lane = column Xb + lane, r[y] = row Pb + y =================
     const int col = Xb + lane - SRX_NPAD;
-    const bool col_ok = Xb + lane >= R0x + HLO && Xb + lane < R0x + 64 * NBX - HHI && col >= 0 && col < W;
-    // owned rows of the block: [HLO, 64) in the first, [0, 64 - HHI) in the last -- whole row quads of the state plane (the window's
+    const bool col_ok = Xb + lane >= R0x + HLO && Xb + lane < R0x + 64 * NBX - HHB && col >= 0 && col < W;
+    // owned rows of the block: [HLO, 64) in the first, [0, 64 - HHB) in the last -- whole row quads of the state plane (the window's
     // owned span starts at a multiple of 4 image rows); rows above the image are out of the descriptor's range, rows past it keep 0
     const int H4 = (H + 3) >> 2, W16 = W * 16, vq0 = col_ok ? (((Pb - SRX_NPAD + 2) >> 2) * W + col) * 16 : VOFF_OUT;
     const int ymax = H + SRX_NPAD - Pb;
     const __amdgpu_buffer_rsrc_t rs_s = fused::plane_rsrc(S + (size_t)b * H4 * W * 4, (size_t)H4 * W * 4);
-    constexpr int QA = (HLO - 2) / 4, QB = (64 - HHI - 2) / 4;
-    static_assert((HLO - 2) % 4 == 0 && (64 - HHI - 2) % 4 == 0, "owned spans are whole row quads");
+    constexpr int QA = (HLO - 2) / 4, QB = (64 - HHB - 2) / 4;
+    static_assert((HLO - 2) % 4 == 0 && (64 - HHB - 2) % 4 == 0, "owned spans are whole row quads");
     float hv[64];
     if (s == 0)
         quads_load<QA, 16>(hv, rs_s, vq0, W16);
@@ -881,10 +884,10 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
     const dim3 cgrid(cdiv(W, 256), H4, B);
     hipLaunchKernelGGL(k_btile_copy_in, cgrid, dim3(256), 0, st, hr_init, H, W, H4, S);
     SRX_CHECK_LAUNCH();
-    const dim3 grid(A.nwx, A.nwy, B), blk(NBY * NBX * 64);
+    const dim3 grid(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
         SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
-        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX>), grid, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
+        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
     }
     hipLaunchKernelGGL(k_btile_copy_out, cgrid, dim3(256), 0, st, S, H, W, H4, hr);
     SRX_CHECK_LAUNCH();
