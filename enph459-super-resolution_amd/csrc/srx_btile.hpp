@@ -17,8 +17,9 @@
 //
 // A window spans padded coordinates (SciPy's 12-sample edge pad is DATA here: rows / columns replicated after the blur, which makes
 // the steady-state start of every recursion exact at an image edge -- the pad is a constant run -- and |z|^11 of the signal's
-// deviation at an interior edge, the tile kernels' R = 11).  Halo: 3 (blur) + 11 before, 3 + 11 + 3 (the FIR's reach) + 1 after; a
-// window owns the LR samples whose tap origin, and the HR pixels whose padded coordinate, lie in [R0 + 14, R0 + 64 NB - 18).
+// deviation at an interior edge, the tile kernels' R = 11).  Halo: 3 (blur) + 11 before, 3 + 11 + 3 (the FIR's reach) + 1 after: a
+// forward window owns the LR samples whose tap origin lies in [R0 + 14, R0 + 64 NB - 18); the backward kernel needs 14 + 14 and its
+// windows own the HR pixels whose padded coordinate lies in [R0 + 14, R0 + 64 NB - 14) (its own, coarser grid of windows).
 // Both pad corrections of the back-projection (np.pad(mode='edge') of the ZERO-INSERTED residual repeats LR row / column 0 on
 // every pad sample, not on every other one) are closed forms on the first window row / column.
 #pragma once

@@ -56,8 +56,8 @@ typedef enum {
 #define SRX_FLAG_COMPOSED 1u /* force the literal per-frame composition of the primitives */
 #define SRX_FLAG_FUSED 2u    /* require a fused path; SRX_E_UNSUPPORTED if not eligible */
 #define SRX_FLAG_PER_FRAME 4u /* fused, but never the "mosaic" (common-fraction, depth-to-space) formulation */
-#define SRX_FLAG_TILES 8u     /* mosaic formulation on the tile kernels only: neither the patch-resident kernel (one workgroup per
-                               * 256x256 HR patch) nor the one-launch-per-iteration kernel for integer HR shifts */
+#define SRX_FLAG_TILES 8u     /* the tile kernels only: none of the register-resident kernels (the patch-resident one, the one-launch frame
+                               * kernels of the mosaic formulation, the window kernels of the per-frame formulation) */
 /* Diagnostic path switches: each selects between implementations that the tests hold to the same results.  They are call
  * arguments (no environment variable alters what a call computes). */
 #define SRX_FLAG_DIAG_NO_ZERO_FUSE 0x100u      /* delta = 0: separate blur and index-map kernels */
@@ -72,7 +72,9 @@ const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
  * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch), "ztile" (mosaic
  * formulation at integer HR shifts on frames of at least 128x128: one launch per iteration on register-resident tiles),
- * "mosaic" (all shifts share one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "fused"
+ * "ctile" (the same in float64, rank-1 PSF), "dtile" (a common fraction > 0 on frames of at least 256x256: one launch per iteration on
+ * overlapping windows), "mosaic" (all shifts share one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "btile"
+ * (per-frame fractional shifts at x2, float32, rank-1 PSF: two launches per iteration on register-resident windows), "fused"
  * (per-frame tile kernels), "composed" (primitives, frame by frame). */
 const char *srx_last_path(void);
 
