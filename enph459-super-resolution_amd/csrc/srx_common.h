@@ -90,6 +90,8 @@ enum KernelId {
     KID_IBP_CTILE,
     KID_IBP_BFWD,
     KID_IBP_BBWD,
+    KID_IBP_AFWD,
+    KID_IBP_ABWD,
     KID_COUNT
 };
 

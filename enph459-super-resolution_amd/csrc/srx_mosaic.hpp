@@ -58,6 +58,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
                    double scale, double *errors, hipStream_t st);
 }  // namespace dtile
+namespace atile {  // srx_atile.hpp: the same frames as two launches per iteration on 2 x 2-wave windows of padded coordinates
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline size_t tabs_bytes(int B, int N, int H, int W);
+static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st);
+}  // namespace atile
 namespace patch {
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
@@ -1067,7 +1075,7 @@ __global__ void __launch_bounds__(256)
 // one of them uses (M, C, Mu, the tap tables, the near-band lists):
 //   tiles : the blurred plane, G, per-tile MSE partials      patch : srx_patch.hpp's operand planes and tables
 //   ztile : srx_ztile.hpp's padded state / operand planes and tables
-enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3, IMPL_CTILE = 4 };
+enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3, IMPL_CTILE = 4, IMPL_ATILE = 5 };
 
 static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
@@ -1077,6 +1085,8 @@ static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, co
         return IMPL_CTILE;
     if (ztile::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_ZTILE;
+    if ((call_flags() & SRX_FLAG_DIAG_TWO_LAUNCH) && atile::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_ATILE;
     if (dtile::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_DTILE;
     return IMPL_TILES;
@@ -1103,6 +1113,8 @@ static inline size_t ws_impl(Impl im, int eb, int B, int N, int H, int W)
         return dtile::tabs_bytes(B, N, H, W);
     if (im == IMPL_CTILE)
         return ctile::tabs_bytes(eb, B, N, H, W);
+    if (im == IMPL_ATILE)
+        return atile::tabs_bytes(B, N, H, W);
     return align_up((size_t)B * Hp * Wp * eb) + align_up((size_t)B * Hg * Wg * eb) +
            align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
@@ -1119,6 +1131,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
         m = std::max(m, ws_impl(IMPL_DTILE, eb, B, N, H, W));
     if (H >= 128 && W >= 128)
         m = std::max(m, ws_impl(IMPL_CTILE, eb, B, N, H, W));
+    if (eb == 4 && H >= 32 && W >= 32)
+        m = std::max(m, ws_impl(IMPL_ATILE, eb, B, N, H, W));
     return ws_common(eb, B, N, H, W) + m;
 }
 
@@ -1138,7 +1152,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
     const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
-    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : "mosaic";  // what srx_last_path() reports: the branch taken
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : impl == IMPL_ATILE ? "atile" : "mosaic";  // what srx_last_path() reports: the branch taken
     Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
     const int NS = (N + 3) & ~3;                        // slots per near-band pixel
@@ -1216,6 +1230,9 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         if (impl == IMPL_ZTILE)
             return ztile::iterate(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale,
                                   errors, st);
+        if (impl == IMPL_ATILE)
+            return atile::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors,
+                                  st);
     }
     constexpr int TS = TileCfg<T>::T_HR;
     // timing ablations (results are wrong / an occupancy cap): compile-time only, -DSRX_ABLATE=<bits> -DSRX_ABLATE_LDS=<bytes>
