@@ -71,6 +71,8 @@ def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
         "k_ibp_ztile": 2 * hw + lrn,            # one launch = one iteration
         "k_ibp_dtile": 2 * hw + lrn,
         "k_ibp_ctile": 2 * hw + lrn,
+        "k_ibp_afwd": 2 * hw + lrn,             # read hr + the LR mosaic, write G
+        "k_ibp_abwd": 3 * hw,                   # read G + hr, write hr
         "k_ibp_bfwd": hw + 2 * lrn,             # read hr + the LR frames, write the residuals
         "k_ibp_bbwd": lrn + 2 * hw,             # read the residuals + hr, write hr
     }.get(name)

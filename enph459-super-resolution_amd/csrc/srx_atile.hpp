@@ -44,6 +44,9 @@ using btile::XW;
 using btile::zero_outside;
 using patch::RW;
 
+#ifndef SRX_AT_DBG
+#define SRX_AT_DBG 0  // timing ablations of a development build (results are wrong): 1 no operand loads, 2 no G stores, 4 no G loads (backward)
+#endif
 struct AArgs {
     int H, W, Hg, Wg, nwx, nwy;  // (nwx, nwy: the FORWARD kernel's windows)
     int Dy, Dx, PBy, PBx;        // G[p', q'] pairs with Y[p' - Dy, q' - Dx]; p' < PBy or q' < PBx: near band
@@ -92,13 +95,100 @@ __global__ void __launch_bounds__(256) k_atile_copy_out(const float *__restrict_
             dst[c] = v[c];
 }
 
+// ---- G and the operand planes with FOUR ROWS interleaved (column layout: lane = column, 16 bytes per lane and instruction):
+//   Gq [b][p' >> 2][q'][p' & 3]            MCq[b][p' >> 2][q'][p' & 3][2] = (M, C)
+// 64 + 64 one-word loads and 64 stores per window wave were the forward kernel (51 us per iteration on 3072 x 4096), 67 loads the backward.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// grid (ceil(Wg / 64), Qn, B), block 64
+__global__ void __launch_bounds__(64) k_atile_prep(const float *__restrict__ Mg, const float *__restrict__ Cg, int Hg, int Wg, int Qn,
+                                                   float *__restrict__ MCq)
+{
+    const int q = blockIdx.x * 64 + threadIdx.x, Q = blockIdx.y, b = blockIdx.z;
+    if (q >= Wg)
+        return;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int p = 4 * Q + c;
+        v[2 * c] = p < Hg ? Mg[((size_t)b * Hg + p) * Wg + q] : 0.f;
+        v[2 * c + 1] = p < Hg ? Cg[(size_t)p * Wg + q] : 0.f;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(MCq) + (((size_t)b * Qn + Q) * Wg + q) * 2;
+    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// The far-field step of the forward kernel on the row quads of a block.  Quad j holds G rows 4 (Qb + j) + c, i.e. block rows
+// y = 4 j + c - OFF (OFF = (Pb + Dy) & 3: 0 or 1).  Rows [Y0, Y1) are owned (CHK: [y0, y1) at run time: windows on the plane's edges).
+template <int OFF, int Y0, int Y1, bool CHK> struct FarQuads {
+    static constexpr int J0 = CHK ? 0 : (Y0 + OFF) / 4, J1 = CHK ? 17 : (Y1 - 1 + OFF) / 4 + 1;  // quads with an owned row
+    static __device__ __forceinline__ bool on(int y, int y0, int y1) { return y >= 0 && y < 64 && (CHK ? (y >= y0 && y < y1) : (y >= Y0 && y < Y1)); }
+    static __device__ __forceinline__ void load1(float (&m)[8], __amdgpu_buffer_rsrc_t rsMC, int voff)
+    {
+        if (SRX_AT_DBG & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                m[i] = (i & 1) ? 1.f : __int_as_float(voff & 0xff);
+            return;
+        }
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsMC, voff, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsMC, voff + 16, 0, 0);
+        m[0] = __uint_as_float(a.x), m[1] = __uint_as_float(a.y), m[2] = __uint_as_float(a.z), m[3] = __uint_as_float(a.w);
+        m[4] = __uint_as_float(b.x), m[5] = __uint_as_float(b.y), m[6] = __uint_as_float(b.z), m[7] = __uint_as_float(b.w);
+    }
+    // the operands of the owned quads, requested ahead of the V stage (the checked form of an edge window loads quad by quad in step():
+    // its 17 quads on top of the plane's registers would spill)
+    static __device__ __forceinline__ void load(float (&mc)[17][8], __amdgpu_buffer_rsrc_t rsMC, int vmc0, int Wg32)
+    {
+        if (CHK)
+            return;
+#pragma unroll
+        for (int j = J0; j < J1; j++)
+            load1(mc[j], rsMC, vmc0 + j * Wg32);
+    }
+    static __device__ __forceinline__ void step(float (&mc)[17][8], const float (&c)[64], __amdgpu_buffer_rsrc_t rsMC, int vmc0, int Wg32,
+                                                __amdgpu_buffer_rsrc_t rsG, int vg0, int Wg16, int y0, int y1, float &sq)
+    {
+#pragma unroll
+        for (int j = J0; j < J1; j++) {
+            if (CHK)
+                load1(mc[0], rsMC, vmc0 + j * Wg32);
+            const float(&m8)[8] = mc[CHK ? 0 : j];
+            float g[4];
+            bool all = !CHK;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int y = 4 * j + q - OFF;
+                const bool o = on(y, y0, y1);
+                all = all && (y >= Y0 && y < Y1 && y >= 0 && y < 64);
+                const float M = m8[2 * q], C = m8[2 * q + 1];
+                g[q] = (o && C > 0.f) ? fmaf(-C, c[(y >= 0 && y < 64) ? y : 0], M) : 0.f;
+                sq = fmaf(g[q] * g[q], mosaic::rcp_count(C), sq);
+            }
+            if (SRX_AT_DBG & 2) {
+                if (g[0] + g[1] + g[2] + g[3] == 123.456f)
+                    fused::buf_store<float>(g[0], rsG, vg0, 0);
+            } else if (all) {
+                const u32x4 v = {__float_as_uint(g[0]), __float_as_uint(g[1]), __float_as_uint(g[2]), __float_as_uint(g[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsG, vg0 + j * Wg16, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (on(4 * j + q - OFF, y0, y1))
+                        fused::buf_store<float>(g[q], rsG, vg0 + j * Wg16 + 4 * q, 0);
+            }
+        }
+    }
+};
+
 // =========================================================================================================================
 // forward.  grid (nwx, nwy, B), block 256
 // =========================================================================================================================
 template <int NBY, int NBX>
 __global__ void __launch_bounds__(NBY *NBX * 64, 2)
-    k_ibp_afwd(const float *__restrict__ S, const float *__restrict__ Mg, const float *__restrict__ Cg, float *__restrict__ G,
-               float *__restrict__ Yb, AArgs A, double *__restrict__ epart, double scale)
+    k_ibp_afwd(const float *__restrict__ S, const float *__restrict__ MCq, float *__restrict__ Gq, float *__restrict__ Yb, AArgs A,
+               double *__restrict__ epart, double scale)
 {
     using L = Lds<NBY, NBX>;
     __shared__ float lds[L::WORDS];
@@ -137,60 +227,35 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
     const int X = Xb + lane, qg = X + A.Dx;
     const bool lane_ok = X >= Xa && X < Xe && qg >= A.PBx && qg < Wg;
     const int y0 = max(max(Ya, A.PBy - A.Dy) - Pb, 0), y1 = min(min(Ye, Hg - A.Dy) - Pb, 64);  // owned far-field rows, block-local
-    const int vg0 = lane_ok ? ((Pb + A.Dy) * Wg + qg) * 4 : VOFF_OUT, Wg4 = Wg * 4;
-    const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(Mg + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
-    const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(Cg, (size_t)Hg * Wg);
-    const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(G + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+    const int Qn = (Hg + 3) >> 2, Qb = (Pb + A.Dy) >> 2, off = (Pb + A.Dy) & 3;  // (Pb = 2 mod 4, Dy in {2, 3}: off in {0, 1})
+    const int vg0 = lane_ok ? (Qb * Wg + qg) * 16 : VOFF_OUT, Wg16 = Wg * 16;
+    const __amdgpu_buffer_rsrc_t rsMC = fused::plane_rsrc(MCq + (size_t)b * Qn * Wg * 8, (size_t)Qn * Wg * 8);
+    const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(Gq + (size_t)b * Qn * Wg * 4, (size_t)Qn * Wg * 4);
+    const int vmc0 = lane_ok ? (Qb * Wg + qg) * 32 : VOFF_OUT, Wg32 = Wg * 32;
     constexpr int YA0 = HLO, YB1 = 64 - HHI;
-    const int sel = (y0 == (s == 0 ? YA0 : 0) && y1 == (s == NBY - 1 ? YB1 : 64)) ? (s == 0 ? 1 : (s == NBY - 1 ? 2 : 3)) : 0;
-    float mv[64], cv[64];
-    auto ldmc = [&](auto lo, auto hi_, auto chk) {
-        constexpr int Y0 = decltype(lo)::value, Y1 = decltype(hi_)::value;
-        constexpr bool CHK = decltype(chk)::value;
-#pragma unroll
-        for (int y = Y0; y < Y1; y++) {
-            const int voff = (!CHK || (y >= y0 && y < y1)) ? vg0 + y * Wg4 : VOFF_OUT;
-            mv[y] = fused::buf_load<float>(rsM, voff, 0);
-            cv[y] = fused::buf_load<float>(rsC, voff, 0);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I64 = std::integral_constant<int, 64>;
-    using IA = std::integral_constant<int, YA0>;
-    using IB = std::integral_constant<int, YB1>;
-    if (sel == 0)
-        ldmc(I0{}, I64{}, std::true_type{});
-    else if (sel == 1)
-        ldmc(IA{}, I64{}, std::false_type{});
-    else if (sel == 2)
-        ldmc(I0{}, IB{}, std::false_type{});
-    else if (NBY > 2)
-        ldmc(I0{}, I64{}, std::false_type{});
+    const int rsel = (y0 == (s == 0 ? YA0 : 0) && y1 == (s == NBY - 1 ? YB1 : 64)) ? (s == 0 ? 1 : (s == NBY - 1 ? 2 : 3)) : 0;
+    const int sel = rsel * 2 + off;  // (row range, quad offset): one of eight static forms
+    float mc[17][8];
+#define SRX_AT_FORMS(WHAT, ...)                                                   \
+    switch (sel) {                                                                \
+    case 0: FarQuads<0, 0, 64, true>::WHAT(__VA_ARGS__); break;                   \
+    case 1: FarQuads<1, 0, 64, true>::WHAT(__VA_ARGS__); break;                   \
+    case 2: FarQuads<0, YA0, 64, false>::WHAT(__VA_ARGS__); break;                \
+    case 3: FarQuads<1, YA0, 64, false>::WHAT(__VA_ARGS__); break;                \
+    case 4: FarQuads<0, 0, YB1, false>::WHAT(__VA_ARGS__); break;                 \
+    case 5: FarQuads<1, 0, YB1, false>::WHAT(__VA_ARGS__); break;                 \
+    case 6: if (NBY > 2) FarQuads<0, 0, 64, false>::WHAT(__VA_ARGS__); break;     \
+    default: if (NBY > 2) FarQuads<1, 0, 64, false>::WHAT(__VA_ARGS__); break;    \
+    }
+    SRX_AT_FORMS(load, mc, rsMC, vmc0, Wg32);
     blur_block(c, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kby));
     edge_replicate(c, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
     prefilter_block(c, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_B, lane, hi);
     fir_after(c, hi, A.wfy);
     // ---- G = M - C Y on the owned far-field pixels; sum g^2 / C
     float sq = 0.f;
-    auto gstep = [&](auto lo, auto hi_, auto chk) {
-        constexpr int Y0 = decltype(lo)::value, Y1 = decltype(hi_)::value;
-        constexpr bool CHK = decltype(chk)::value;
-#pragma unroll
-        for (int y = Y0; y < Y1; y++) {
-            const bool on = !CHK || (y >= y0 && y < y1);
-            const float g = cv[y] > 0.f ? fmaf(-cv[y], c[y], mv[y]) : 0.f;
-            fused::buf_store<float>(g, rsG, on ? vg0 + y * Wg4 : VOFF_OUT, 0);
-            sq = fmaf(g * g, mosaic::rcp_count(cv[y]), sq);  // (a pixel that is not owned read M = C = 0: g = 0)
-        }
-    };
-    if (sel == 0)
-        gstep(I0{}, I64{}, std::true_type{});
-    else if (sel == 1)
-        gstep(IA{}, I64{}, std::false_type{});
-    else if (sel == 2)
-        gstep(I0{}, IB{}, std::false_type{});
-    else if (NBY > 2)
-        gstep(I0{}, I64{}, std::false_type{});
+    SRX_AT_FORMS(step, mc, c, rsMC, vmc0, Wg32, rsG, vg0, Wg16, y0, y1, sq);
+#undef SRX_AT_FORMS
     // ---- the rows / columns of Y the near band's lists name (owned positions only: each is written once)
     const int PYB = A.PBy - A.Dy + 1, PXB = A.PBx - A.Dx + 1;  // (a replicated sample pairs with Y row E - n_k <= PB - D)
     if (Pb < PYB || Xb < PXB) {
@@ -240,7 +305,7 @@ __global__ void __launch_bounds__(256)
             const int cc = nyx[(size_t)idx * NS + e];
             ys += Y[(size_t)(cc & 0xffff) * Wy + (cc >> 16)];
         }
-        G[((size_t)b * Hg + p) * Wg + q] = Mg[((size_t)b * Hg + p) * Wg + q] - ys;
+        G[(((size_t)b * ((Hg + 3) >> 2) + (p >> 2)) * Wg + q) * 4 + (p & 3)] = Mg[((size_t)b * Hg + p) * Wg + q] - ys;
         if (cu > 0) {
             const float gu = Mu[(size_t)b * NB + idx] - (float)cu * Y[(size_t)max(p - A.Dy, 0) * Wy + max(q - A.Dx, 0)];
             sq = gu * gu / (float)cu;
@@ -298,13 +363,26 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
     // ================= column layout: lane = G column Xb + lane, registers = G rows Pb + y (three more than the block) =================
     float g[67];
     {
-        const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(G + (size_t)b * Hg * Wg, (size_t)Hg * Wg);
+        const int Qn = (Hg + 3) >> 2;
+        const __amdgpu_buffer_rsrc_t rsG = fused::plane_rsrc(G + (size_t)b * Qn * Wg * 4, (size_t)Qn * Wg * 4);
         const int q = Xb + lane;
-        const int vq = q < Wg ? max(q, 0) * 4 : VOFF_OUT;  // (columns left of the plane repeat column 0: all frames' pads)
+        // (columns left of the plane repeat column 0 -- all frames' pads; rows above it row 0: below)
+        const int Wg16 = Wg * 16, vq0 = q < Wg ? (((Pb + 2) >> 2) * Wg + max(q, 0)) * 16 : VOFF_OUT;  // the quad of y = 2..5 (Pb = 2 mod 4)
+        {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsG, vq0 - Wg16 + 8, 0, 0);
+            g[0] = __uint_as_float(t.x), g[1] = __uint_as_float(t.y);
+        }
 #pragma unroll
-        for (int y = 0; y < 67; y++) {
-            const int p = Pb + y;  // wave-uniform
-            g[y] = fused::buf_load<float>(rsG, p < Hg ? vq + max(p, 0) * Wg * 4 : VOFF_OUT, 0);
+        for (int j = 0; j < 16; j++) {
+            const u32x4 t = (SRX_AT_DBG & 4) ? u32x4{(unsigned)j, 0x3f800000u, (unsigned)vq0 & 0xffu, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rsG, vq0 + j * Wg16, 0, 0);
+            g[2 + 4 * j] = __uint_as_float(t.x), g[3 + 4 * j] = __uint_as_float(t.y), g[4 + 4 * j] = __uint_as_float(t.z), g[5 + 4 * j] = __uint_as_float(t.w);
+        }
+        g[66] = fused::buf_load<float>(rsG, vq0 + 16 * Wg16, 0);
+        if (Pb < 0) {  // Pb == -HLO: the rows above the plane
+            const float g0 = fused::buf_load<float>(rsG, q < Wg ? max(q, 0) * 16 : VOFF_OUT, 0);
+#pragma unroll
+            for (int y = 0; y < HLO; y++)
+                g[y] = g0;
         }
     }
     float v[64];
@@ -376,7 +454,9 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
     (void)N;
     const size_t Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
     const size_t nwin = (size_t)cdiv((int)Hp + 1, Geo<2, 2>::OWNY) * cdiv((int)Wp + 1, Geo<2, 2>::OWNX), nnear = cdiv((int)(20 * (Hg + Wg)), 256);
-    return align_up((size_t)B * ((W + 3) / 4) * H * 16) + align_up((size_t)B * Hg * Wg * 4) + align_up((size_t)B * (Hp + 4) * (Wp + 4) * 4) +
+    const size_t Qn = (Hg + 3) / 4;
+    return align_up((size_t)B * ((W + 3) / 4) * H * 16) + align_up((size_t)B * Qn * Wg * 16) + align_up((size_t)B * Qn * Wg * 32) +
+           align_up((size_t)B * (Hp + 4) * (Wp + 4) * 4) +
            align_up((size_t)B * (nwin + nnear) * sizeof(double));
 }
 
@@ -395,7 +475,9 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     A.nnear = cdiv(NB, 256);
     A.sn = (float)step / (float)N;
     float *S = ar.take<float>((size_t)B * W4 * H * 4);
-    float *G = ar.take<float>((size_t)B * Hg * Wg);
+    const int Qn = (Hg + 3) / 4;
+    float *G = ar.take<float>((size_t)B * Qn * Wg * 4);       // four rows interleaved
+    float *MCq = ar.take<float>((size_t)B * Qn * Wg * 8);     // (M, C), four rows interleaved
     float *Yb = ar.take<float>((size_t)B * (Hp + 4) * (Wp + 4));
     double *epart = ar.take<double>((size_t)B * (A.nwx * A.nwy + A.nnear));
     if (!ar.ok)
@@ -424,9 +506,13 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     const dim3 cgrid(cdiv(W4, 64), cdiv(H, 4), B), cblk(64, 4);
     hipLaunchKernelGGL(k_atile_copy_in, cgrid, cblk, 0, st, hr_init, H, W, W4, S);
     SRX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_atile_prep, dim3(cdiv(Wg, 64), Qn, B), dim3(64), 0, st, Mg, Cg, Hg, Wg, Qn, MCq);
+    SRX_CHECK_LAUNCH();
+    if (hipMemsetAsync(G, 0, (size_t)B * Qn * Wg * 16, st) != hipSuccess)  // (the rows of the last quad past the plane are read, never written)
+        return SRX_E_HIP;
     const dim3 gridf(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
-        SRX_LAUNCH(KID_IBP_AFWD, (k_ibp_afwd<NBY, NBX>), gridf, blk, 0, st, S, Mg, Cg, G, Yb, A, errors ? epart : nullptr, scale);
+        SRX_LAUNCH(KID_IBP_AFWD, (k_ibp_afwd<NBY, NBX>), gridf, blk, 0, st, S, MCq, G, Yb, A, errors ? epart : nullptr, scale);
         hipLaunchKernelGGL(k_atile_near, dim3(A.nnear, B), dim3(256), 0, st, Mg, Mu, ncu, nyx, NS, NB, Yb, G, A, errors ? epart : nullptr, scale);
         SRX_CHECK_LAUNCH();
         SRX_LAUNCH(KID_IBP_ABWD, (k_ibp_abwd<NBY, NBX>), gridb, blk, 0, st, G, S, A, epart, Vtot, scale, errors ? errors + it : nullptr, n_iter);

@@ -65,7 +65,7 @@ typedef enum {
 #define SRX_FLAG_DIAG_NO_PREFILTER_TILE 0x400u /* line prefilter kernels for float planes */
 #define SRX_FLAG_DIAG_WIDE_WINDOWS 0x1000u     /* delta != 0 frames: 256-column windows whatever the plan's cost model says */
 #define SRX_FLAG_DIAG_COLUMN_TILES 0x2000u    /* delta = 0 frames in float32: the transpose-free kernel (float64's default) instead of k_ibp_ztile */
-#define SRX_FLAG_DIAG_TWO_LAUNCH 0x4000u     /* common-fraction frames: the two-launch window kernels (srx_atile.hpp) instead of k_ibp_dtile / the tiles */
+#define SRX_FLAG_DIAG_TWO_LAUNCH 0x4000u     /* common-fraction frames: the two-launch window kernels (srx_atile.hpp) also where k_ibp_dtile would run */
 #define SRX_FLAG_DIAG_V1 0x800u                /* per-frame fused path with stand-alone prefilter passes (8 launches / iteration) */
 
 int srx_version(void);

@@ -345,6 +345,8 @@ def test_fused_path_vs_oracle(prec, cfg):
     close(saa_p[0].cpu().numpy(), saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
     want64 = "ctile" if (want_ibp == "ztile" and psf_name == "gauss") else want  # float64: the transpose-free frame kernel (rank-1 PSFs)
+    if want_ibp == "mosaic" and psf_name == "gauss":
+        want_ibp = "atile"  # float32, rank-1 PSF, a common fraction > 0 on a frame k_ibp_dtile does not take: the two-launch window kernels
     assert S.last_path() == (want_ibp if prec == "f32" else want64)
     close(hr, hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
@@ -704,8 +706,8 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert torch.equal(one[0], hr[3]) and torch.equal(e1[0], errs[3])
     S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # non-separable PSF
     assert S.last_path() == "mosaic"
-    S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR
-    assert S.last_path() == "mosaic"
+    S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR: the two-launch window kernels
+    assert S.last_path() == "atile"
     S.ibp_batched(lr_d[:1].double(), shifts, psf, saa_d[:1].double(), f, 2, 0.5, precision="f64")
     assert S.last_path() == "mosaic"
 
@@ -924,6 +926,90 @@ def test_full_size_rgb_frame_paths_agree():
     assert torch.equal(hr2[0], hr_d[0]) and torch.equal(e2[0], e_d[0])
 
 
+ATILE_CFGS = {
+    # name: (factor, shifts, (h, w) LR, flags)
+    "x4_ph16_small": (4, _PH4, (40, 50), 0),                     # 160 x 200 HR: a frame k_ibp_dtile does not take (two-launch kernels by default)
+    "x4_ph16_forced": (4, _PH4, (80, 100), "two"),                # ... and one it does, on request
+    "x2_ph4_ragged": (2, synth.phase_shifts(2), (90, 131), 0),   # W = 262: not a multiple of 16
+    "x4_lattice": (4, [_PH4[0], _PH4[5], _PH4[6], _PH4[6], _PH4[15]], (64, 77), 0),   # two frames on one phase (counts of 2), W = 308
+    "x2_mixed": (2, [(0.5, 0.25), (-0.5, -0.25), (0.0, 0.75)], (90, 120), 0),           # y integer, x fraction 0.5
+    "x3_frac": (3, [(0.1, 0.4), (0.1 + 1.0 / 3, 0.4 - 2.0 / 3), (0.1 - 1.0 / 3, 0.4 + 1.0 / 3)], (50, 66), 0),  # x3, fractions 0.3 / 0.2
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(ATILE_CFGS))
+def test_two_launch_window_kernels_vs_oracle(cfg):
+    """k_ibp_afwd / k_atile_near / k_ibp_abwd (frames with a common fraction, two launches per iteration on 2 x 2-wave windows) against the
+    oracle after 1, 2 and 6 iterations (state and MSE trace), against the tile kernels, in place, as a batch."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, (h, w), fl = ATILE_CFGS[cfg]
+    flags = S.FLAG_DIAG_TWO_LAUNCH if fl == "two" else S.FLAG_AUTO
+    psf = synth.gaussian_psf()
+    O.set_threads(16)
+    try:
+        lrs, saas = [], []
+        for i in range(2):
+            truth = synth.truth_image(h * f, w * f, seed=520 + i)
+            lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=620 + i)
+            lrs.append(lr), saas.append(O.shift_and_add(list(lr), shifts, f))
+        lr, saa = np.stack(lrs), np.stack(saas)
+        for n in (1, 2, 6):
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5, flags=flags)
+            assert S.last_path() == "atile"
+            for i in range(2 if n == 6 else 1):
+                hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
+                close(hr[i].cpu().numpy(), hr_o, IBP_TOL["f32"])
+                np.testing.assert_allclose(errs[i].cpu().numpy(), err_o, rtol=ERR_RTOL["f32"])
+    finally:
+        O.set_threads(1)
+    hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_TILES)
+    assert S.last_path() == "mosaic"
+    assert float((hr - hr_t).abs().max()) < 5e-4
+    np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    buf = torch.from_numpy(saa).cuda().float()
+    hr2, errs2 = S.ibp_batched(lr, shifts, psf, buf, f, 6, 0.5, flags=flags, out=buf)
+    assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
+    one, e1 = S.ibp_batched(lr[1:2], shifts, psf, saa[1:2], f, 6, 0.5, flags=flags)
+    assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
+
+
+def test_two_launch_window_kernels_80_iterations_and_full_size():
+    """80 iterations on a frame of several windows against the oracle; SURVEY 8d's C3-f4 at full size against k_ibp_dtile."""
+    from oracle import sr_oracle as O
+    S.set_precision("f32")
+    f, shifts, psf, (h, w) = 4, _PH4, synth.gaussian_psf(), (60, 77)
+    O.set_threads(16)
+    try:
+        truth = synth.truth_image(h * f, w * f, seed=73)
+        lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=74)
+        saa_o = O.shift_and_add(list(lr), shifts, f)
+        hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, 80, 0.5)
+    finally:
+        O.set_threads(1)
+    hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 80, 0.5, verbose=False)
+    assert S.last_path() == "atile"
+    close(hr, hr_o, IBP_TOL["f32"])
+    np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL["f32"])
+    assert synth.psnr(hr, hr_o) > 90.0 and abs(synth.psnr(hr, truth) - synth.psnr(hr_o, truth)) < 0.01
+    u8_close(hr, hr_o)
+    x = torch.from_numpy(synth.truth_image(384, 512, seed=25)).cuda().float().repeat(8, 8)[None].contiguous()
+    lrf = torch.stack([S.forward_model_batched(x, psf, s, f) for s in shifts], dim=1).contiguous()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(8)
+    lrn = torch.clamp(torch.round(lrf + 2.0 * torch.randn(lrf.shape, generator=gen, device="cuda")), 0, 255)
+    saa = S.shift_and_add_batched(lrn, shifts, f)
+    hr_d, e_d = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5)
+    assert S.last_path() == "dtile"
+    hr_a, e_a = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_DIAG_TWO_LAUNCH)
+    assert S.last_path() == "atile"
+    assert float((hr_d - hr_a).abs().max()) < 5e-4
+    np.testing.assert_allclose(e_d.cpu().numpy(), e_a.cpu().numpy(), rtol=2e-6)
+    for _ in range(2):
+        hr_r, e_r = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_DIAG_TWO_LAUNCH)
+        assert torch.equal(hr_r, hr_a) and torch.equal(e_r, e_a)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Parity holes named by the round-1 review
 # ---------------------------------------------------------------------------------------------------------
@@ -951,7 +1037,7 @@ def test_80_iterations_multi_tile(prec, cfg):
     finally:
         O.set_threads(1)
     hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 80, 0.5, flags=flags)
-    assert S.last_path() == want
+    assert S.last_path() == ("atile" if (want == "mosaic" and prec == "f32") else want)  # (float32, rank-1 PSF: the two-launch window kernels)
     close(hr[0].cpu().numpy(), hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
 

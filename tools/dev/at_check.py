@@ -22,7 +22,7 @@ for ci, (f, shifts, (h, w)) in enumerate(cases):
     saa_o = O.shift_and_add(list(lr), shifts, f)
     for n in (1, 2, 6):
         hr_o, err_o = O.ibp(list(lr), shifts, psf, saa_o, f, n, 0.5)
-        hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, n, 0.5, flags=S.FLAG_DIAG_TWO_LAUNCH)
+        hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, n, 0.5, flags=S.FLAG_AUTO)
         path = S.last_path()
         hr = hr[0].cpu().numpy(); errs = errs[0].cpu().numpy()
         d = np.abs(hr - hr_o)
