@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
     const float *Xup = Xown - NBX * XW, *Xdn = Xown + NBX * XW, *Xlf = Xown - XW, *Xrt = Xown + XW;
     float *edge = lds + L::OFF_EDGE;
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
+    SRX_PSTAMP(0);
     // ================= row layout: lane = row Pb + lane, a[x] = column Xb + x =================
     float a[64];
     {
@@ -214,13 +215,18 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
         const int H16 = H * 16, vq0 = rowok ? (((Xb - SRX_NPAD + 2) >> 2) * H + row) * 16 : VOFF_OUT;
         quads_load<-1, 16>(a, rs, vq0, H16);
     }
+    SRX_PSTAMP(1);
     float hi[3];
     blur_block(a, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.kbx));
+    SRX_PSTAMP(2);
     edge_replicate(a, Xb, W + SRX_NPAD - 1, R0x + 64 * NBX - 1 > W + SRX_NPAD - 1, edge + 64 * s + lane);
     prefilter_block(a, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_B, lane, hi);
+    SRX_PSTAMP(3);
     fir_after(a, hi, A.wfx);
+    SRX_PSTAMP(4);
     float c[64];
     transpose64(a, c, Rown, lane);
+    SRX_PSTAMP(5);
     // ================= column layout: lane = column Xb + lane, c[y] = row Pb + y =================
     // the far-field operands of this block's owned rows: requested here, consumed behind the V stage
     const int Ya = R0y + HLO, Ye = R0y + 64 * NBY - HHI, Xa = R0x + HLO, Xe = R0x + 64 * NBX - HHI;  // owned Y positions
@@ -248,14 +254,19 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
     default: if (NBY > 2) FarQuads<1, 0, 64, false>::WHAT(__VA_ARGS__); break;    \
     }
     SRX_AT_FORMS(load, mc, rsMC, vmc0, Wg32);
+    SRX_PSTAMP(6);
     blur_block(c, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kby));
+    SRX_PSTAMP(7);
     edge_replicate(c, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
     prefilter_block(c, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_B, lane, hi);
+    SRX_PSTAMP(8);
     fir_after(c, hi, A.wfy);
+    SRX_PSTAMP(9);
     // ---- G = M - C Y on the owned far-field pixels; sum g^2 / C
     float sq = 0.f;
     SRX_AT_FORMS(step, mc, c, rsMC, vmc0, Wg32, rsG, vg0, Wg16, y0, y1, sq);
 #undef SRX_AT_FORMS
+    SRX_PSTAMP(10);
     // ---- the rows / columns of Y the near band's lists name (owned positions only: each is written once)
     const int PYB = A.PBy - A.Dy + 1, PXB = A.PBx - A.Dx + 1;  // (a replicated sample pairs with Y row E - n_k <= PB - D)
     if (Pb < PYB || Xb < PXB) {
@@ -269,6 +280,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, 2)
             fused::buf_store<float>(c[y], rsY, on ? (P * Wy + X) * 4 : VOFF_OUT, 0);
         }
     }
+    SRX_PSTAMP(11);
     if (epart) {
         const double ws = wave_sum((double)sq);
         if (lane == 0)

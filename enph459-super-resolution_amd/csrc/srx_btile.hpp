@@ -36,6 +36,11 @@ using patch::PZ;
 using patch::RW;
 using patch::ZP;
 
+#ifdef SRX_STAMPS_INNER  // stamps inside prefilter_block (the last call of a kernel wins)
+#define SRX_PSTAMP2(PH) SRX_PSTAMP(PH)
+#else
+#define SRX_PSTAMP2(PH) do { } while (0)
+#endif
 #ifndef SRX_BT_PREFETCH
 #define SRX_BT_PREFETCH 1  // the forward kernel's LR samples requested ahead of the H-FIR and the transpose
 #endif
@@ -89,9 +94,12 @@ __device__ __forceinline__ f8 ld8(const float *p)
 __device__ __forceinline__ void prefilter_block(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext,
                                                 int slot, int lane, float (&hi)[3])
 {
+    SRX_PSTAMP2(16);
     chain64<false>(a, first ? a[0] * K2 : 0.f);
     Rown[slot + lane] = a[63];
+    SRX_PSTAMP2(17);
     __syncthreads();
+    SRX_PSTAMP2(18);
     if (!first) {
         const float carry = Rprev[slot + lane];
 #pragma unroll
@@ -103,7 +111,9 @@ __device__ __forceinline__ void prefilter_block(float (&a)[64], bool first, bool
     Rown[slot + 64 + lane] = a[0];
     Rown[slot + 128 + lane] = a[1];
     Rown[slot + 192 + lane] = a[2];
+    SRX_PSTAMP2(19);
     __syncthreads();
+    SRX_PSTAMP2(20);
     hi[0] = hi[1] = hi[2] = cb;
     if (!last) {
         const float hb = Rnext[slot + 64 + lane];
