@@ -145,6 +145,9 @@ static inline bool plan(int H, int W, Plan &pl)
     return true;
 }
 
+// the superset of every shape plan() admits whatever the call flags say: what the shape-only workspace bound tests
+static inline bool shape_ok(int H, int W) { return H >= RY && W >= 64 * 3 && H % ALIGN_Y == 0 && W % ALIGN_X == 0; }
+
 static inline void axis_span(const mosaic::AxisPlan &pl, int N, int &ex, int &nb)
 {
     int nmin = pl.n[0], nmax = pl.n[0];

@@ -51,6 +51,7 @@ static int iterate(const T *hr_init, T *hr, int B, int N, const mosaic::AxisPlan
                    const double *Vtot, Arena &ar, int H, int W, int n_iter, double step, double scale, double *errors, hipStream_t st);
 }  // namespace ctile
 namespace dtile {  // srx_dtile.hpp: a common fraction > 0 on large frames, overlapping register-resident windows, one launch per iteration
+static inline bool shape_ok(int H, int W);  // a window plan exists for the shape under SOME call flags (the workspace bound's predicate)
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
 static inline size_t tabs_bytes(int B, int N, int H, int W);
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
@@ -1129,7 +1130,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
         m = std::max(m, ws_impl(IMPL_PATCH, eb, B, N, H, W));
     if (eb == 4 && H >= 128 && W >= 128)
         m = std::max(m, ws_impl(IMPL_ZTILE, eb, B, N, H, W));
-    if (eb == 4 && H >= 256 && W >= 256 && H % 4 == 0 && W % 16 == 0)
+    // every shape dtile::plan() admits: 256-row windows of 192 (4 x 3 waves) or 256 columns, origins on row quads / 16-column groups
+    if (eb == 4 && dtile::shape_ok(H, W))
         m = std::max(m, ws_impl(IMPL_DTILE, eb, B, N, H, W));
     if (H >= 128 && W >= 128)
         m = std::max(m, ws_impl(IMPL_CTILE, eb, B, N, H, W));

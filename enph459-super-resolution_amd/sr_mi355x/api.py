@@ -206,8 +206,10 @@ def shift_and_add_batched(lr, shifts_yx, factor=2, precision=None, flags=FLAG_AU
 
 
 def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, precision=None, flags=FLAG_AUTO,
-                want_errors=True, out=None):
-    """lr [B, N, h, w], hr_init [B, H, W] -> (hr [B, H, W], errors float64 [B, n_iter] or None)."""
+                want_errors=True, out=None, exact_workspace=True):
+    """lr [B, N, h, w], hr_init [B, H, W] -> (hr [B, H, W], errors float64 [B, n_iter] or None).
+    `exact_workspace=False` sizes the arena by the shape-only bound (srx_ibp_workspace_bytes), as a caller without the shift table
+    at hand would."""
     prec = precision or get_precision()
     x, _ = _to_dev(lr, prec)
     h0, _ = _to_dev(hr_init, prec)
@@ -224,7 +226,9 @@ def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, p
             raise ValueError(f"out must be a contiguous CUDA tensor of dtype {_TORCH_DT[prec]} and shape {(B, H, W)}")
     hr = torch.empty_like(h0) if out is None else out
     errors = torch.empty((B, int(n_iter)), dtype=torch.float64, device=x.device) if want_errors else None
-    wt, wp, wn = _ws(_lib.load().srx_ibp_workspace_bytes_for(_ELEM[prec], B, N, h, w, H, W, f, shp, kp, k.shape[0], k.shape[1], flags))
+    lib = _lib.load()
+    wt, wp, wn = _ws(lib.srx_ibp_workspace_bytes_for(_ELEM[prec], B, N, h, w, H, W, f, shp, kp, k.shape[0], k.shape[1], flags)
+                     if exact_workspace else lib.srx_ibp_workspace_bytes(_ELEM[prec], B, N, h, w, H, W, f, flags))
     _lib.check(_fn("srx_ibp", prec)(_p(x), B, N, h, w, shp, kp, k.shape[0], k.shape[1], _p(h0), H, W, f, int(n_iter),
                                     float(step), _p(hr), _p(errors) if want_errors else None, wp, wn, _stream(), flags),
                "srx_ibp")

@@ -48,3 +48,35 @@ def test_argument_validation_without_gpu():
     assert lib.srx_u8_to_f32(None, 0, None, None) == _lib.E_INVALID
     assert lib.srx_ibp_f64(None, 1, 4, 8, 8, None, None, 7, 7, None, 16, 16, 2, 1, 0.5, None, None, None, 0, None,
                            0) == _lib.E_INVALID
+
+
+def test_exact_workspace_never_exceeds_the_shape_bound():
+    """srx_ibp_workspace_bytes (shape only) must cover srx_ibp_workspace_bytes_for (shifts + PSF at hand) whatever
+    implementation the call picks: a caller that sizes its arena once by the bound may not see SRX_E_WORKSPACE.
+    (Round 3 shipped a bound that forgot k_ibp_dtile's 4 x 3-wave windows: HR widths 192..255.)"""
+    import ctypes
+    import numpy as np
+    from sr_mi355x import synth
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    psfs = [synth.gaussian_psf(), synth.asymmetric_psf()]
+    worst = 0.0
+    for f, shift_sets in ((2, (synth.NOMINAL_4, synth.NOMINAL_5, synth.MEASURED_4, synth.phase_shifts(2))),
+                          (3, (synth.phase_shifts(3),)), (4, (synth.phase_shifts(4), synth.NOMINAL_4))):
+        for shifts in shift_sets:
+            sh = np.ascontiguousarray(np.asarray(shifts, dtype=np.float64))
+            N = len(shifts)
+            for H in (32, 64, 96, 128, 132, 192, 252, 256, 260, 320, 512, 1024):
+                for W in (32, 64, 128, 176, 192, 208, 224, 240, 256, 272, 512, 1040):
+                    if H % f or W % f:
+                        continue
+                    for psf in psfs:
+                        k = np.ascontiguousarray(psf)
+                        for eb in (4, 8):
+                            for B in (1, 3):
+                                bound = lib.srx_ibp_workspace_bytes(eb, B, N, H // f, W // f, H, W, f, 0)
+                                need = lib.srx_ibp_workspace_bytes_for(eb, B, N, H // f, W // f, H, W, f, sh.ctypes.data_as(dp),
+                                                                       k.ctypes.data_as(dp), 7, 7, 0)
+                                assert 0 < need <= bound, (f, N, H, W, eb, B, need, bound)
+                                worst = max(worst, need / bound)
+    assert worst <= 1.0

@@ -723,6 +723,7 @@ DTILE_CFGS = {
     "x4_ph16_float": (4, _PH4, (80, 100), "wide", False),                 # fractional samples: the float mosaic
     "x4_ph16_3x3win": (4, _PH4, (160, 176), 0, True),                     # interior windows (no image edge on any side)
     "x2_ph4": (2, synth.phase_shifts(2), (150, 232), 0, True),            # n in {-1, 0}: nothing above / left of the image
+    "x2_ph4_w240": (2, synth.phase_shifts(2), (128, 120), 0, True),       # HR 256 x 240: ONE 4 x 3-wave window; the arena sized by the shape-only bound
     "x4_n01": (4, [s for s in _PH4 if s[0] > 0 and s[1] > 0], (80, 100), 0, True),       # n in {0, 1}: samples above the image, no near band inside
     "x4_sub12": (4, [s for s in _PH4 if s[0] > -0.3], (80, 100), "wide", True),           # 3 x 4 product grid
     "x4_lattice": (4, [_PH4[0], _PH4[5], _PH4[6], _PH4[6], _PH4[15]], (64, 112), 0, False),  # two frames on one phase: the count plane
@@ -748,7 +749,7 @@ def test_frame_fraction_kernel_vs_oracle(cfg):
             lrs.append(lr), saas.append(O.shift_and_add(list(lr), shifts, f))
         lr, saa = np.stack(lrs), np.stack(saas)
         for n in (1, 2, 6):
-            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5, flags=flags)
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5, flags=flags, exact_workspace=(n != 2))
             assert S.last_path() == "dtile"
             for i in range(2 if n == 6 else 1):
                 hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
@@ -767,11 +768,13 @@ def test_frame_fraction_kernel_vs_oracle(cfg):
     assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
 
 
-def test_frame_fraction_kernel_80_iterations():
-    """80 iterations of the x4 / 16-phase workload on a frame of several windows, against the oracle (the north-star tolerances)."""
+@pytest.mark.parametrize("shape", [(80, 100), (160, 176)])
+def test_frame_fraction_kernel_80_iterations(shape):
+    """80 iterations of the x4 / 16-phase workload on a frame of several windows -- 2 x 4 edge windows, and 3 x 5 with windows that
+    touch no image edge -- against the oracle (the north-star tolerances)."""
     from oracle import sr_oracle as O
     S.set_precision("f32")
-    f, shifts, psf, (h, w) = 4, _PH4, synth.gaussian_psf(), (80, 100)
+    f, shifts, psf, (h, w) = 4, _PH4, synth.gaussian_psf(), shape
     O.set_threads(16)
     try:
         truth = synth.truth_image(h * f, w * f, seed=71)
@@ -1008,6 +1011,59 @@ def test_two_launch_window_kernels_80_iterations_and_full_size():
     for _ in range(2):
         hr_r, e_r = S.ibp_batched(lrn, shifts, psf, saa, f, 6, 0.5, flags=S.FLAG_DIAG_TWO_LAUNCH)
         assert torch.equal(hr_r, hr_a) and torch.equal(e_r, e_a)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: REFERENCE-generated goldens for the window kernels (tools/make_golden.py --only-windows)
+# ---------------------------------------------------------------------------------------------------------
+WIN_RGB_PATH = {"g": "btile", "m": "fused"}  # the implementation each PSF of rgb_cal_target must reach in float32
+
+
+@pytest.mark.parametrize("psf_tag", ["g", "m"])
+def test_window_golden_rgb_crop(prec, psf_tag):
+    """What rgb_cal_target actually feeds the path-B window kernels: rep-averaged (non-integer) red frames of its committed session
+    through extract_red + rep mean, its measured shifts, its ibp for its 50 iterations with the default Gaussian PSF and with
+    --psf measured (rgb_cal_target/run_sr.py:59, :78-113, :128-166, :204-223), generated by the reference itself."""
+    from conftest import load_golden
+    g = load_golden("win_btile.npz")
+    S.set_precision("f64")  # loader arithmetic bit-exactly in float64
+    lr = np.stack([S.mean_frames(np.stack([S.extract_red(r.astype(np.float64)) for r in reps])) for reps in g["raw"]])
+    S.set_precision(prec)
+    assert lr.shape == (4, 64, 96) and np.abs(lr - np.rint(lr)).max() > 0.1  # non-integer frames
+    sh, psf, init = g["shifts"], g[f"psf_{psf_tag}"], g["saa"].astype(np.float64)
+    close(S.shift_and_add(list(lr), sh, 2), init, PRIM_TOL[prec] + 2e-5)  # stored as float32
+    hr, errs = S.ibp(list(lr), sh, psf, init, 2, 50, 0.5, verbose=False)
+    assert S.last_path() == (WIN_RGB_PATH[psf_tag] if prec == "f32" else "fused")
+    close(hr, g[f"ibp50_{psf_tag}"], IBP_TOL["f32"])
+    np.testing.assert_allclose(errs, g[f"errors_{psf_tag}"], rtol=ERR_RTOL[prec])
+    u8_close(hr, g[f"ibp50_{psf_tag}"].astype(np.float64))
+    if psf_tag == "g":
+        hr1, e1 = S.ibp(list(lr), sh, psf, init, 2, 1, 0.5, verbose=False)
+        close(hr1, g["ibp1_g"], IBP_TOL["f32"])
+
+
+@pytest.mark.parametrize("name", ["win_dtile", "win_dtile_float", "win_atile"])
+def test_window_golden_phase_grids(name):
+    """x4 / 16 phases through the reference's ibp for 80 iterations: 288 x 320 HR (2 x 2 windows of k_ibp_dtile, byte mosaic;
+    half-integer frames: its float mosaic) and 160 x 200 HR (the two-launch window kernels)."""
+    from conftest import load_golden
+    g = load_golden(name + ".npz")
+    S.set_precision("f32")
+    want = "atile" if name == "win_atile" else "dtile"
+    lr = g["lr16"].astype(np.float64) if "lr16" in g else 0.5 * (g["lr16_a"].astype(np.float64) + g["lr16_b"].astype(np.float64))
+    sh, psf, init = g["shifts16"], g["psf_g"], g["saa16"].astype(np.float64)
+    close(S.shift_and_add(list(lr), sh, 4), init, PRIM_TOL["f32"])
+    for n in (1, 10, 80):
+        if f"ibp16_{n}" not in g:
+            continue
+        hr, errs = S.ibp(list(lr), sh, psf, init, 4, n, 0.5, verbose=False)
+        assert S.last_path() == want
+        close(hr, g[f"ibp16_{n}"], IBP_TOL["f32"])
+        np.testing.assert_allclose(errs, g["ibp16_errors"][:n], rtol=ERR_RTOL["f32"])
+    u8_close(hr, g["ibp16_80"].astype(np.float64))
+    truth = synth.truth_image(init.shape[0], init.shape[1], seed=int(g["truth_seed"]))
+    ref = g["ibp16_80"].astype(np.float64)
+    assert synth.psnr(hr, ref) > 90.0 and abs(synth.psnr(hr, truth) - synth.psnr(ref, truth)) < 0.01
 
 
 # ---------------------------------------------------------------------------------------------------------

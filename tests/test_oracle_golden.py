@@ -176,3 +176,49 @@ def test_interleave4_known_answer():
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interleave4_3x3.npz"))
     assert np.array_equal(O.interleave4(g["frames"]), g["expected"])
+
+
+# ---- round 4: reference-generated goldens sized for the window kernels (tools/make_golden.py --only-windows) ----
+F32_STORE = 2e-5  # big outputs are stored as float32 (half an ulp at 255 is 7.6e-6)
+
+
+def _win_rgb_frames(g):
+    """extract_red (rgb_cal_target/run_sr.py:73-75) + rep mean (:107-108) from the raw Bayer crops of every rep"""
+    raw = g["raw"].astype(np.float64)  # [4 corners, R reps, 2h, 2w]
+    return [np.mean(np.stack([r[0::2, 0::2] for r in reps]), axis=0) for reps in raw]
+
+
+@pytest.mark.parametrize("psf_tag", ["g", "m"])
+def test_window_golden_rgb_crop(psf_tag):
+    """rgb_cal_target's own inputs (rep-averaged, non-integer red frames; measured shifts) for its 50 iterations with the default
+    Gaussian PSF and with --psf measured (rgb_cal_target/run_sr.py:59, :128-166, :204-223)."""
+    from conftest import load_golden
+    g = load_golden("win_btile.npz")
+    lr, sh = _win_rgb_frames(g), g["shifts"]
+    close(O.shift_and_add(lr, sh, 2), g["saa"], F32_STORE)
+    init = g["saa"].astype(np.float64)
+    O.set_threads(8)
+    try:
+        hr, errs = O.ibp(lr, sh, g[f"psf_{psf_tag}"], init, 2, 50, 0.5)
+    finally:
+        O.set_threads(1)
+    close(hr, g[f"ibp50_{psf_tag}"], F32_STORE)
+    np.testing.assert_allclose(errs, g[f"errors_{psf_tag}"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["win_dtile", "win_dtile_float", "win_atile"])
+def test_window_golden_phase_grids(name):
+    """x4, all 16 phases, 80 iterations of the reference's ibp (mono_cal_target/run_sr.py:190-209) on 288 x 320 HR (integer and
+    half-integer frames) and 160 x 200 HR."""
+    from conftest import load_golden
+    g = load_golden(name + ".npz")
+    lr = g["lr16"].astype(np.float64) if "lr16" in g else 0.5 * (g["lr16_a"].astype(np.float64) + g["lr16_b"].astype(np.float64))
+    sh, init = g["shifts16"], g["saa16"].astype(np.float64)
+    O.set_threads(8)
+    try:
+        close(O.shift_and_add(list(lr), sh, 4), g["saa16"], F32_STORE)
+        hr, errs = O.ibp(list(lr), sh, g["psf_g"], init, 4, 80, 0.5)
+    finally:
+        O.set_threads(1)
+    close(hr, g["ibp16_80"], F32_STORE)
+    np.testing.assert_allclose(errs, g["ibp16_errors"], rtol=1e-10)

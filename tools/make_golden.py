@@ -8,6 +8,7 @@ Only arrays (inputs + expected outputs) are written; no reference source travels
 
     python tools/make_golden.py                  # writes tests/golden/
     python tools/make_golden.py --only-frames    # only frame_zero.npz (round 3)
+    python tools/make_golden.py --only-windows   # only win_btile / win_dtile / win_atile.npz (round 4)
 """
 import contextlib
 import glob
@@ -80,6 +81,62 @@ def frame_goldens(mono, psf_g, psf_m):
     np.savez_compressed(os.path.join(OUT, "frame_zero.npz"), **d)
 
 
+def window_goldens(mono, rgb, psf_g, psf_m):
+    """Round 4: reference-generated goldens LARGE enough for the three window kernels (the round-3 review: they were held to the
+    oracle only).  Four files, each <= ~1 MB (inputs uint8, big outputs float32, every hr_init the float32-ROUNDED shift_and_add so
+    that the stored init is exactly what the reference iterated from):
+      win_btile.npz  a 64 x 96 red-LR crop of the committed rgb_cal_target frames through the reference's load_combo (rep means:
+                     non-integer frames; measured shifts; rgb_cal_target/run_sr.py:78-113) and its ibp for its 50 iterations with
+                     the DEFAULT Gaussian PSF (:59, :204-223) and with the measured, non-separable PSF (--psf measured, :128-166)
+      win_dtile.npz  72 x 80 LR at x4, all 16 phases (288 x 320 HR = 2 x 2 windows): ibp at 1 / 80 iterations + the 80-entry trace
+                     (mono_cal_target/run_sr.py:190-209); win_dtile_float.npz: the same with half-integer frames (mean of two sensor
+                     draws), 80 iterations
+      win_atile.npz  40 x 50 LR at x4, all 16 phases (160 x 200 HR): 1 / 10 / 80 iterations"""
+    f32 = np.float32
+    # ---- (a) rgb_cal_target crop ----
+    combo = glob.glob(os.path.join(REF, "rgb_cal_target", "data", "*"))[0]
+    frames, shifts = quiet(rgb.load_combo, combo)
+    h, w, y0, x0 = 64, 96, 352, 470
+    raw = []
+    for idx in range(4):
+        reps = sorted(glob.glob(os.path.join(combo, f"corner{idx}_rep*.png")))
+        raw.append(np.stack([np.array(Image.open(r))[2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)] for r in reps]))
+    crop = [fr[y0:y0 + h, x0:x0 + w].copy() for fr in frames]
+    saa = rgb.shift_and_add(crop, shifts, factor=2, order=3)
+    init = saa.astype(f32).astype(np.float64)
+    d = dict(raw=np.stack(raw), shifts=np.array(shifts), psf_g=psf_g, psf_m=psf_m, saa=saa.astype(f32), crop_yx=np.array([y0, x0]))
+    for tag, psf in (("g", psf_g), ("m", psf_m)):
+        hr, errs = quiet(rgb.ibp, crop, shifts, psf, init.copy(), factor=2, n_iter=50, step=0.5)
+        d[f"ibp50_{tag}"], d[f"errors_{tag}"] = hr.astype(f32), np.asarray(errs)
+    hr, _ = quiet(rgb.ibp, crop, shifts, psf_g, init.copy(), factor=2, n_iter=1, step=0.5)
+    d["ibp1_g"] = hr.astype(f32)
+    np.savez_compressed(os.path.join(OUT, "win_btile.npz"), **d)
+    # ---- (b), (c): x4 phase grids ----
+    ph = synth.phase_shifts(4)
+    for name, (h, w), seed in (("win_dtile", (72, 80), 31), ("win_atile", (40, 50), 33)):
+        f = 4
+        truth = synth.truth_image(h * f, w * f, seed=synth.SEED_TRUTH + seed)
+        lr = make_lr(mono, truth, psf_g, ph, f, synth.SEED_NOISE + seed)
+        saa = mono.shift_and_add(list(lr), ph, factor=f, order=3)
+        init = saa.astype(f32).astype(np.float64)
+        tr, errs = ibp_trace(mono, lr, ph, psf_g, init, f, (1, 10, 80))
+        # (truth is synth.truth_image(h * f, w * f, seed=truth_seed): numpy only, regenerated by the tests)
+        d = dict(truth_seed=np.array(synth.SEED_TRUTH + seed), psf_g=psf_g, shifts16=np.array(ph), lr16=lr.astype(np.uint8),
+                 saa16=saa.astype(f32), ibp16_1=tr[1].astype(f32), ibp16_80=tr[80].astype(f32), ibp16_errors=errs)
+        if name == "win_atile":
+            d["ibp16_10"] = tr[10].astype(f32)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        if name == "win_dtile":  # half-integer frames: the float form of the mosaic (k_ibp_dtile<false, .>)
+            lr_b = make_lr(mono, truth, psf_g, ph, f, synth.SEED_NOISE + seed + 1)
+            lrh = 0.5 * (lr + lr_b)
+            saa = mono.shift_and_add(list(lrh), ph, factor=f, order=3)
+            init = saa.astype(f32).astype(np.float64)
+            hr, errs = quiet(mono.ibp, list(lrh), ph, psf_g, init.copy(), factor=f, n_iter=80, step=0.5)
+            np.savez_compressed(os.path.join(OUT, "win_dtile_float.npz"), truth_seed=d["truth_seed"], psf_g=psf_g, shifts16=np.array(ph),
+                                lr16_a=lr.astype(np.uint8), lr16_b=lr_b.astype(np.uint8), saa16=saa.astype(f32), ibp16_80=hr.astype(f32),
+                                ibp16_errors=np.asarray(errs))
+
+
 def write_manifest(meta):
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as fp:
         json.dump({"generated_by": "tools/make_golden.py", "reference": "benedikthoward/ENPH459-Super-Resolution",
@@ -97,7 +154,12 @@ def main():
     psf_g = quiet(mono.make_gaussian_psf)
     psf_m = quiet(mono.load_measured_psf, os.path.join(REF, "calibration_beam_shift", "data"))
     meta = {"scipy": __import__("scipy").__version__, "numpy": np.__version__}
+    if "--only-windows" in sys.argv:  # round 4: the window kernels' files; everything else stays byte for byte
+        window_goldens(mono, rgb, psf_g, psf_m)
+        write_manifest(meta)
+        return
     frame_goldens(mono, psf_g, psf_m)
+    window_goldens(mono, rgb, psf_g, psf_m)
     if "--only-frames" in sys.argv:  # the other files are unchanged since round 1: leave them byte for byte
         write_manifest(meta)
         return
