@@ -53,7 +53,8 @@ using patch::ZP;
 constexpr int HLO = 14, HHI = 18;  // halo before / after the owned span (forward kernel: 3 blur + 11 | 3 FIR reach + 11 + 3 + 1)
 constexpr int HHB = 14;            // ... after the owned span of the backward kernel (11 + 3): its windows own 100 x 100, a tenth fewer of them
 constexpr int MAXF = 16;           // frames per call
-constexpr int SLOT_A = 0, SLOT_B = 384, XW = 640;  // a wave's exchange slots: blur (6 x 64 words), prefilter (4 x 64)
+constexpr int SLOT_A = 0, SLOT_B = 384, SLOT_C = 640, XW = 1152;  // a wave's exchange slots: blur (6 x 64 words), prefilter (4 x 64), the 7 x 7
+                                                                   // blur's edge columns (64 rows x 8 words)
 
 struct BFrame {  // 20 words
     int oyf, oxf;  // forward: sim[i, j] = sum wyf[a] wxf[b] c[2 i + oyf + a, 2 j + oxf + b] (padded coordinates)
@@ -67,6 +68,8 @@ struct BArgs {
     float sn;              // step / N
     float kby[8], kbx[8];  // forward blur (correlation) weights, times kq
     float kty[8], ktx[8];  // backward blur (flipped kernel) weights
+    float k2f[56], k2b[56];  // a PSF that is not rank 1: the 7 x 7 correlation weights of the forward (times kq^2) / backward blur, row v of the
+                             // PSF as eight words in blur2d_rows' pairing: K[v][0], [1] | [4], [5] | [6], [2] | [3], 0
     BFrame fr[MAXF];
 };
 
@@ -78,7 +81,8 @@ template <int NBY, int NBX> struct Lds {
     static constexpr int OFF_EDGE = OFF_SL + NW * XW;        // replicated edge sample, one per line: [max(NBY, NBX) * 64]
     static constexpr int OFF_FR = OFF_EDGE + (NBY > NBX ? NBY : NBX) * 64;
     static constexpr int OFF_PART = OFF_FR + MAXF * 20;
-    static constexpr int WORDS = OFF_PART + 2 * NW + 2;
+    static constexpr int OFF_ZERO = (OFF_PART + 2 * NW + 2 + 3) & ~3;  // 512 zero words: what a window's outer waves read as their neighbours' edge columns
+    static constexpr int WORDS = OFF_ZERO + 512;
     static_assert(WORDS * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -220,6 +224,112 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
+}
+
+// ---- 7 x 7 correlation of a block in COLUMN layout (lane = column, registers = rows) for a PSF that is not rank 1 ------------------
+// (rgb_cal_target --psf measured, rgb_cal_target/run_sr.py:128-166: the measured PSF has singular values 0.41 / 0.03 / 0.003 ...)
+// out[y][x] = sum_{v, u} K[v][u] in[y + v - 3][x + u - 3].  The rows of the PSF run along the registers, its columns along the LANES:
+// every input row is shifted six times by one lane (v_mov_b32_dpp wave_shr:1 / wave_shl:1) and each of its seven copies feeds the
+// seven output rows it reaches -- (S0, S1), (S4, S5), (S6, S2) as v_pk_fma_f32 against scalar-register pairs of weights, S3 (the row
+// itself) as a plain fma: 6 + 28 instructions per row for 49 multiply-adds per pixel.  An output row is a PAIR of partial sums until
+// its last input row has gone by.  What a shift pulls in at the end of a wave is the neighbour wave's edge column: the DPP move's `old`
+// operand, one 16-byte LDS read per row (every wave publishes its columns 0..2 and 63..61 for all 64 rows before the one barrier;
+// a window's outer waves read zeros, as blur_block does).  Rows come from the blocks above / below as in blur_block, their edge
+// columns from the diagonal neighbours' published rows.
+__device__ __forceinline__ float dpp_up(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_dn(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+
+// input row R of the block (R = -3 .. 66; a template recursion: `#pragma unroll` gave up part-way and indexed the registers dynamically).
+// e0 / e1: the edge columns of rows R and R + 1 (requested two rows ahead of their use: an LDS read right in front of its shifts cost
+// the LDS latency per row).
+template <int R> __device__ __forceinline__ float4 blur2d_edge(const float *eU, const float *eM, const float *eD)
+{
+    return *reinterpret_cast<const float4 *>(R < 0 ? eU + 8 * (64 + R) : (R < 64 ? eM + 8 * (R & 63) : eD + 8 * (R - 64)));
+}
+template <int R>
+__device__ __forceinline__ void blur2d_rows(float (&a)[64], v2f (&acc)[7], const float (&hl)[3], const float (&hr)[3], const float *eU, const float *eM,
+                                            const float *eD, const f8 (&kv)[7], float4 e, float4 e1)
+{
+    float4 e2 = e1;
+    if constexpr (R + 2 <= 66)
+        e2 = blur2d_edge<R + 2>(eU, eM, eD);
+    const float in = R < 0 ? hl[R < 0 ? R + 3 : 0] : (R < 64 ? a[R >= 0 && R < 64 ? R : 0] : hr[R >= 64 ? R - 64 : 0]);
+    const float s2 = dpp_up(in, e.x), s1 = dpp_up(s2, e.y), s0 = dpp_up(s1, e.z);
+    const float s4 = dpp_dn(in, e.x), s5 = dpp_dn(s4, e.y), s6 = dpp_dn(s5, e.z);
+    // (the pairs follow the registers the shifts leave their results in: the down chain overwrites the three words of the LDS read in
+    // place, its fourth word is where s2 goes)
+    const v2f p01 = {s0, s1}, p45 = {s4, s5}, p62 = {s6, s2};
+    // pair-major: the seven output rows' instructions of one pair are independent of each other (a dependent VALU instruction issues
+    // ~11 cycles behind its producer, and one or two waves per SIMD do not fill that gap)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int v = 0; v < 7; v++) {
+            const int o = R - v + 3;  // the output row this PSF row feeds
+            if (o < 0 || o > 63)
+                continue;
+            const f8 k = kv[v];
+            v2f &A = acc[(o + 7) % 7];
+            if (q == 0) {
+                if (v == 0)  // the output's first input row
+                    A = (v2f){k[0], k[1]} * p01;
+                else
+                    A = __builtin_elementwise_fma((v2f){k[0], k[1]}, p01, A);
+            } else if (q == 1)
+                A = __builtin_elementwise_fma((v2f){k[2], k[3]}, p45, A);
+            else if (q == 2)
+                A = __builtin_elementwise_fma((v2f){k[4], k[5]}, p62, A);
+            else
+                A.x = fmaf(k[6], in, A.x);
+        }
+    }
+    if constexpr (R >= 3) {  // output row R - 3 has seen its last input row
+        const v2f A = acc[(R - 3) % 7];
+        a[R - 3] = A.x + A.y;
+        asm volatile("" : "+v"(a[R - 3]));
+    }
+    // Row by row.  An opaque use of every partial sum right here: left alone the multiply-adds of an output row are SUNK to where the row is
+    // complete (six input rows later: 49 shifted copies live instead of 7, ~340 spilled registers), and the scheduler issues the LDS reads
+    // and shifts of many rows up front.
+#pragma unroll
+    for (int v = 0; v < 7; v++) {
+        const int o = R - v + 3;
+        if (o >= 0 && o <= 63 && v < 6)
+            asm volatile("" : "+v"(acc[(o + 7) % 7]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (R < 66)
+        blur2d_rows<R + 1>(a, acc, hl, hr, eU, eM, eD, kv, e1, e2);
+}
+
+__device__ __forceinline__ void blur2d_cross(float (&a)[64], bool sfirst, bool slast, bool ufirst, bool ulast, float *Xown, const float *Xup, const float *Xdn,
+                                             const float *zero, int lane, const f8 (&kv)[7])
+{
+    Xown[SLOT_A + lane] = a[0];
+    Xown[SLOT_A + 64 + lane] = a[1];
+    Xown[SLOT_A + 128 + lane] = a[2];
+    Xown[SLOT_A + 192 + lane] = a[61];
+    Xown[SLOT_A + 256 + lane] = a[62];
+    Xown[SLOT_A + 320 + lane] = a[63];
+    if (lane < 3 || lane > 60) {  // row i: words 0..2 = columns 0, 1, 2; words 4..6 = columns 63, 62, 61 (the order a neighbour shifts them in)
+        float *pub = Xown + SLOT_C + (lane < 3 ? lane : 67 - lane);
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            pub[8 * i] = a[i];
+    }
+    __syncthreads();
+    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+    if (!sfirst)
+        hl[0] = Xup[SLOT_A + 192 + lane], hl[1] = Xup[SLOT_A + 256 + lane], hl[2] = Xup[SLOT_A + 320 + lane];
+    if (!slast)
+        hr[0] = Xdn[SLOT_A + lane], hr[1] = Xdn[SLOT_A + 64 + lane], hr[2] = Xdn[SLOT_A + 128 + lane];
+    // where this lane finds the columns a shift pulls in: lane 0 the left neighbour's 63, 62, 61, lane 63 the right neighbour's 0, 1, 2
+    const bool l0 = lane == 0, l63 = lane == 63;
+    const float *eM = l0 ? (ufirst ? zero : Xown - XW + SLOT_C + 4) : (l63 && !ulast ? Xown + XW + SLOT_C : zero);
+    const float *eU = l0 ? (ufirst || sfirst ? zero : Xup - XW + SLOT_C + 4) : (l63 && !ulast && !sfirst ? Xup + XW + SLOT_C : zero);
+    const float *eD = l0 ? (ufirst || slast ? zero : Xdn - XW + SLOT_C + 4) : (l63 && !ulast && !slast ? Xdn + XW + SLOT_C : zero);
+    v2f acc[7];  // output rows r - 3 .. r + 3 of the current input row r, as pairs of partial sums: acc[o % 7]
+    blur2d_rows<-3>(a, acc, hl, hr, eU, eM, eD, kv, blur2d_edge<-3>(eU, eM, eD), blur2d_edge<-2>(eU, eM, eD));
 }
 
 // H-FIR of frame HALF of a pair with decimation: s[32 HALF + j] = sum_b w[b] c[2 j + PAR + b]
@@ -428,13 +538,13 @@ template <int NBY, int NBX> struct Geo {
 // =========================================================================================================================
 // forward: err[b, k, i, j] = lr - (F_k P pad B hr)[2 i, 2 j];  epart[b, window] = sum err^2 * scale.  grid (nwx, nwy, B)
 // =========================================================================================================================
-template <int NBY, int NBX>
+template <int NBY, int NBX, bool SEP>
 __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bfwd(const float *__restrict__ S, const float *__restrict__ lr, float *__restrict__ err, BArgs A, const int *__restrict__ frtab,
                double *__restrict__ epart, double scale)
 {
     using L = Lds<NBY, NBX>;
-    __shared__ float lds[L::WORDS];
+    __shared__ __attribute__((aligned(16))) float lds[L::WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave / NBX, u = wave % NBX;
     int wx, wy, b;
@@ -450,6 +560,11 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
     for (int i = tid; i < N * 20; i += L::NT)  // the frame table where a lane can index it
         frt[i] = frtab[i];
+    const float *zero = lds + L::OFF_ZERO;
+    if (!SEP) {
+        for (int i = tid; i < 512; i += L::NT)
+            lds[L::OFF_ZERO + i] = 0.f;
+    }
     SRX_PSTAMP(0);
     // ================= column layout: lane = column Xb + lane, a[i] = row Pb + i =================
     float a[64];
@@ -463,7 +578,16 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
         quads_load<-1, 16>(a, rs, vq0, W16);
     }
     SRX_PSTAMP(1);
-    blur_block(a, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kby));
+    if (SEP)
+        blur_block(a, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kby));
+    else  // the whole 7 x 7 here, before anything is replicated: rows and columns outside the image were loaded as zeros
+    {
+        f8 kv[7];
+#pragma unroll
+        for (int v = 0; v < 7; v++)
+            kv[v] = ld8(A.k2f + 8 * v);
+        blur2d_cross(a, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
+    }
     SRX_PSTAMP(2);
     edge_replicate(a, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
     float hi[3];
@@ -473,7 +597,8 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     transpose64(a, c, Rown, lane);
     SRX_PSTAMP(4);
     // ================= row layout: lane = row Pb + lane, c[j] = column Xb + j =================
-    blur_block(c, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.kbx));
+    if (SEP)
+        blur_block(c, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.kbx));
     SRX_PSTAMP(5);
     edge_replicate(c, Xb, W + SRX_NPAD - 1, R0x + 64 * NBX - 1 > W + SRX_NPAD - 1, edge + 64 * s + lane);
     prefilter_block(c, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_B, lane, hi);
@@ -600,13 +725,13 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
 // backward: hr_out = clip(hr_in + step * B'( crop P ( sum_k F'_k pad U err_k ) ) / N) on the window's owned pixels.
 // grid (nwx, nwy, B).  The window (0, 0) of an item also sums the forward kernel's per-window MSE partials.
 // =========================================================================================================================
-template <int NBY, int NBX>
+template <int NBY, int NBX, bool SEP>
 __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bbwd(const float *__restrict__ err, float *__restrict__ S, BArgs A, const int *__restrict__ frtab, const double *__restrict__ epart,
                double *__restrict__ errors, int errors_stride)
 {
     using L = Lds<NBY, NBX>;
-    __shared__ float lds[L::WORDS];
+    __shared__ __attribute__((aligned(16))) float lds[L::WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave / NBX, u = wave % NBX;
     int wx, wy, b;
@@ -621,6 +746,11 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     double *part = reinterpret_cast<double *>(lds + L::OFF_PART);
     for (int i = tid; i < N * 20; i += L::NT)
         frt[i] = frtab[i];
+    const float *zero = lds + L::OFF_ZERO;
+    if (!SEP) {
+        for (int i = tid; i < 512; i += L::NT)
+            lds[L::OFF_ZERO + i] = 0.f;
+    }
     __syncthreads();
     if (errors && wx == 0 && wy == 0) {  // MSE trace of this iteration: the forward windows' sums in a fixed order
         const int nwin = A.nwx * A.nwy;  // (the FORWARD kernel's windows)
@@ -769,8 +899,10 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     float hi[3];
     prefilter_block(v, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_B, lane, hi);
     SRX_PSTAMP(17);
-    zero_outside(v, Xb, W + SRX_NPAD - 1);
-    blur_block(v, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.ktx));
+    if (SEP) {
+        zero_outside(v, Xb, W + SRX_NPAD - 1);
+        blur_block(v, u == 0, u == NBX - 1, Xown, Xlf, Xrt, SLOT_A, lane, ld8(A.ktx));
+    }
     SRX_PSTAMP(18);
     float r[64];
     transpose64(v, r, Rown, lane);
@@ -795,7 +927,23 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     prefilter_block(r, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_B, lane, hi);
     SRX_PSTAMP(20);
     zero_outside(r, Pb, H + SRX_NPAD - 1);
-    blur_block(r, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kty));
+    if (SEP)
+        blur_block(r, s == 0, s == NBY - 1, Xown, Xup, Xdn, SLOT_A, lane, ld8(A.kty));
+    else {
+        // the 7 x 7 with the flipped kernel; columns outside the image count as zeros too (the column direction lies along the lanes
+        // here: the prefilter down the columns has left them alone)
+        if (Xb < SRX_NPAD || Xb + 63 > W + SRX_NPAD - 1) {
+            const bool colin = col >= 0 && col < W;
+#pragma unroll
+            for (int i = 0; i < 64; i++)
+                r[i] = colin ? r[i] : 0.f;
+        }
+        f8 kv[7];
+#pragma unroll
+        for (int v = 0; v < 7; v++)
+            kv[v] = ld8(A.k2b + 8 * v);
+        blur2d_cross(r, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
+    }
     SRX_PSTAMP(21);
     {
         const float sn = A.sn;
@@ -815,13 +963,11 @@ static inline bool eligible(int elem_bytes, int N, int h, int w, const double *s
     if (elem_bytes != 4 || f != 2 || N > MAXF || H != 2 * h || W != 2 * w || H < 32 || W < 32 || (size_t)H * W >= (1u << 28) ||
         (size_t)N * h * w >= (1u << 28))
         return false;
-    if (call_flags() & (SRX_FLAG_TILES | SRX_FLAG_DIAG_V1 | SRX_FLAG_DIAG_NO_SEPARABLE))
+    if (call_flags() & (SRX_FLAG_TILES | SRX_FLAG_DIAG_V1))
         return false;
     if (!fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f))
         return false;
-    fused::Kernel7<float> kc;
-    fused::make_kernel7<float>(k, kh, kw, false, kc);
-    return kc.separable != 0;
+    return kh <= 7 && kw <= 7;  // a rank-1 PSF as 7 + 7 taps, any other 7 x 7 along registers and lanes (blur2d_cross)
 }
 
 static inline size_t ws_bytes(int B, int N, int h, int w, int H, int W)
@@ -864,6 +1010,14 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
         A.kby[i] = (float)(kq * (double)kc.cy[i]), A.kbx[i] = (float)(kq * (double)kc.cx[i]);
         A.kty[i] = kt.cy[i], A.ktx[i] = kt.cx[i];
     }
+    const bool sep = kc.separable && kt.separable;
+    static const int pairing[8] = {0, 1, 4, 5, 6, 2, 3, -1};  // blur2d_rows: (S0, S1) (S4, S5) (S6, S2) packed, S3 alone
+    for (int v = 0; v < 7; v++)
+        for (int q = 0; q < 8; q++) {
+            const int uu = pairing[q];
+            A.k2f[8 * v + q] = uu < 0 ? 0.f : (float)(kq * kq * (double)kc.k[7 * v + uu]);
+            A.k2b[8 * v + q] = uu < 0 ? 0.f : kt.k[7 * v + uu];
+        }
     A.oyf_min = A.oyb_min = 1 << 20, A.oyf_max = A.oyb_max = -(1 << 20);
     for (int q = 0; q < MAXF; q++) {
         BFrame &f = A.fr[q];
@@ -897,8 +1051,13 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
     SRX_CHECK_LAUNCH();
     const dim3 grid(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
-        SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
-        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
+        if (sep) {
+            SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX, true>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
+            SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX, true>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
+        } else {
+            SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX, false>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
+            SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX, false>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
+        }
     }
     hipLaunchKernelGGL(k_btile_copy_out, cgrid, dim3(256), 0, st, S, H, W, H4, hr);
     SRX_CHECK_LAUNCH();

@@ -304,7 +304,7 @@ def test_large_image_chunked_prefilter(prec):
 
 FUSED_CFGS = {
     # name: (factor, shifts (LR px), psf, (h, w), expected path)
-    "f2_meas": (2, synth.MEASURED_4, "asym", (150, 277), "fused"),          # distinct sub-pixel fractions: per-frame tiles
+    "f2_meas": (2, synth.MEASURED_4, "asym", (150, 277), "fused", "btile"),  # distinct sub-pixel fractions: per-frame; x2 in float32 on register-resident windows (7 x 7 form)
     "f3_k5": (3, [(0.2, -0.4), (-1.0 / 3, 1.0 / 3), (0.9, 0.1)], "asym5", (60, 75), "fused"),
     "f2_nom5": (2, synth.NOMINAL_5, "gauss", (131, 200), "mosaic", "ztile"),  # integer HR shifts: pure depth-to-space; IBP on CU-resident tiles
     "f2_nom4_big": (2, synth.NOMINAL_4, "gauss", (150, 277), "mosaic", "ztile"),  # several 244-pixel tiles per axis, ragged last tiles
@@ -345,13 +345,14 @@ def test_fused_path_vs_oracle(prec, cfg):
     close(saa_p[0].cpu().numpy(), saa_o, PRIM_TOL[prec])
     hr, errs = S.ibp(list(lr), shifts, psf, saa_o, f, 6, 0.5, verbose=False)
     want64 = "ctile" if (want_ibp == "ztile" and psf_name == "gauss") else want  # float64: the transpose-free frame kernel (rank-1 PSFs)
+    flags_t = S.FLAG_TILES | (S.FLAG_PER_FRAME if want == "fused" else 0)
     if want_ibp == "mosaic" and psf_name == "gauss":
         want_ibp = "atile"  # float32, rank-1 PSF, a common fraction > 0 on a frame k_ibp_dtile does not take: the two-launch window kernels
     assert S.last_path() == (want_ibp if prec == "f32" else want64)
     close(hr, hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs, err_o, rtol=ERR_RTOL[prec])
     if want_ibp != want and prec == "f32":  # the tile kernels of srx_mosaic.hpp on the same input
-        hr_t, errs_t = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_TILES)
+        hr_t, errs_t = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=flags_t)
         assert S.last_path() == want
         close(hr_t[0].cpu().numpy(), hr_o, IBP_TOL[prec])
         np.testing.assert_allclose(errs_t[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
@@ -360,8 +361,8 @@ def test_fused_path_vs_oracle(prec, cfg):
     assert S.last_path() == "composed"
     close(hr_c[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     hr_p, errs_p = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 6, 0.5, flags=S.FLAG_PER_FRAME)
-    # (x2, float32, rank-1 PSF: the per-frame formulation runs on register-resident windows, srx_btile.hpp)
-    assert S.last_path() == ("btile" if prec == "f32" and f == 2 and psf_name == "gauss" else "fused")
+    # (x2, float32, a PSF within 7 x 7: the per-frame formulation runs on register-resident windows, srx_btile.hpp)
+    assert S.last_path() == ("btile" if prec == "f32" and f == 2 else "fused")
     close(hr_p[0].cpu().numpy(), hr, 2 * IBP_TOL[prec])
     np.testing.assert_allclose(errs_p[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
 
@@ -566,7 +567,8 @@ def test_full_frame_paths_agree_and_trace_is_deterministic():
     for f, shifts, psf, tile, reps, want, main, other in (
             (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "ztile", S.FLAG_AUTO, S.FLAG_PER_FRAME),
             (2, synth.NOMINAL_5, synth.gaussian_psf(), (384, 512), (8, 8), "mosaic", S.FLAG_TILES, S.FLAG_PER_FRAME),
-            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "fused", S.FLAG_AUTO, S.FLAG_COMPOSED)):
+            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "btile", S.FLAG_AUTO, S.FLAG_TILES),
+            (2, synth.MEASURED_4, synth.asymmetric_psf(), (384, 512), (4, 4), "fused", S.FLAG_TILES, S.FLAG_COMPOSED)):
         big = torch.from_numpy(synth.truth_image(*tile, seed=6)).cuda().float().repeat(*reps)[None].contiguous()
         lr = torch.stack([S.forward_model_batched(big, psf, s, f) for s in shifts], dim=1)
         lr = torch.clamp(torch.round(lr + 2.0 * torch.randn(lr.shape, generator=gen, device="cuda")), 0, 255).contiguous()
@@ -828,14 +830,26 @@ def test_full_size_x4_frame_paths_agree():
     assert torch.equal(hr2w[0], hr_w[0]) and torch.equal(e2w[0], e_w[0])
 
 
+_FIVE_WIDE = [(0.3, -1.2), (1.7, 0.45), (-1.9, 1.99), (0.0, 0.25), (-0.6, -0.6)]
 BTILE_CFGS = {
-    # name: (shifts (LR px), (h, w) LR)
-    "meas4": (synth.MEASURED_4, (150, 277)),   # the reference's rgb_cal_target shifts: 4 x 6 windows, ragged last windows
-    "five_wide": ([(0.3, -1.2), (1.7, 0.45), (-1.9, 1.99), (0.0, 0.25), (-0.6, -0.6)], (70, 83)),  # odd N (a half-empty pair), |2 s| up to 4, an integer one
-    "tiny": (synth.MEASURED_4, (20, 33)),      # one window; the image ends inside its first block row
-    "smallest": (synth.MEASURED_4, (16, 16)),  # 32 x 32 HR, the smallest frame the kernels take
-    "two_frames": ([(0.37, -0.21), (-0.12, 0.45)], (64, 96)),  # one pair
+    # name: (shifts (LR px), (h, w) LR, PSF)
+    "meas4": (synth.MEASURED_4, (150, 277), "gauss"),   # the reference's rgb_cal_target shifts: 4 x 6 windows, ragged last windows
+    "five_wide": (_FIVE_WIDE, (70, 83), "gauss"),  # odd N (a half-empty pair), |2 s| up to 4, an integer one
+    "tiny": (synth.MEASURED_4, (20, 33), "gauss"),      # one window; the image ends inside its first block row
+    "smallest": (synth.MEASURED_4, (16, 16), "gauss"),  # 32 x 32 HR, the smallest frame the kernels take
+    "two_frames": ([(0.37, -0.21), (-0.12, 0.45)], (64, 96), "gauss"),  # one pair
+    # a PSF that is not rank 1 (rgb_cal_target --psf measured, rgb_cal_target/run_sr.py:128-166): the 7 x 7 along registers and lanes
+    "meas4_asym": (synth.MEASURED_4, (150, 277), "asym"),
+    "five_wide_asym": (_FIVE_WIDE, (70, 83), "asym"),
+    "tiny_asym": (synth.MEASURED_4, (20, 33), "asym"),
+    "smallest_asym5": (synth.MEASURED_4, (16, 16), "asym5"),  # a 5 x 5 kernel embedded in the 7 x 7
+    "meas4_gauss_as_7x7": (synth.MEASURED_4, (90, 140), "gauss7x7"),  # the Gaussian through the 7 x 7 form (SRX_FLAG_DIAG_NO_SEPARABLE)
 }
+
+
+def _btile_psf(kind):
+    a = synth.asymmetric_psf()
+    return {"gauss": synth.gaussian_psf(), "gauss7x7": synth.gaussian_psf(), "asym": a, "asym5": a[1:6, 1:6] / a[1:6, 1:6].sum()}[kind]
 
 
 @pytest.mark.parametrize("cfg", sorted(BTILE_CFGS))
@@ -845,8 +859,9 @@ def test_frame_shift_kernel_vs_oracle(cfg):
     batch, and run to run."""
     from oracle import sr_oracle as O
     S.set_precision("f32")
-    shifts, (h, w) = BTILE_CFGS[cfg]
-    f, psf = 2, synth.gaussian_psf()
+    shifts, (h, w), kind = BTILE_CFGS[cfg]
+    f, psf = 2, _btile_psf(kind)
+    fl = S.FLAG_DIAG_NO_SEPARABLE if kind == "gauss7x7" else S.FLAG_AUTO
     O.set_threads(16)
     try:
         lrs, saas = [], []
@@ -856,7 +871,7 @@ def test_frame_shift_kernel_vs_oracle(cfg):
             lrs.append(lr), saas.append(O.shift_and_add(list(lr), shifts, f))
         lr, saa = np.stack(lrs), np.stack(saas)
         for n in (1, 2, 6):
-            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5)
+            hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5, flags=fl)
             assert S.last_path() == "btile"
             for i in range(2 if n == 6 else 1):
                 hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
@@ -868,19 +883,28 @@ def test_frame_shift_kernel_vs_oracle(cfg):
     assert S.last_path() == "fused"
     assert float((hr - hr_t).abs().max()) < 5e-4
     np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    if kind == "gauss7x7":  # the same PSF through the 7 + 7 form of the same kernels
+        hr_s, e_s = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5)
+        assert S.last_path() == "btile" and float((hr - hr_s).abs().max()) < 2e-4
+        np.testing.assert_allclose(errs.cpu().numpy(), e_s.cpu().numpy(), rtol=2e-6)
     buf = torch.from_numpy(saa).cuda().float()
-    hr2, errs2 = S.ibp_batched(lr, shifts, psf, buf, f, 6, 0.5, out=buf)
+    hr2, errs2 = S.ibp_batched(lr, shifts, psf, buf, f, 6, 0.5, out=buf, flags=fl)
     assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
-    one, e1 = S.ibp_batched(lr[1:2], shifts, psf, saa[1:2], f, 6, 0.5)
+    one, e1 = S.ibp_batched(lr[1:2], shifts, psf, saa[1:2], f, 6, 0.5, flags=fl)
     assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
+    for _ in range(3):  # run to run
+        hr3, errs3 = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5, flags=fl)
+        assert torch.equal(hr, hr3) and torch.equal(errs, errs3)
 
 
-def test_frame_shift_kernel_80_iterations():
-    """The reference's rgb_cal_target defaults (four measured shifts, Gaussian PSF; rgb_cal_target/run_sr.py:171-192, 340-373) for its 50
-    and for 80 iterations on a frame of several windows, against the oracle at the north-star tolerances."""
+@pytest.mark.parametrize("kind", ["gauss", "asym"])
+def test_frame_shift_kernel_80_iterations(kind):
+    """The reference's rgb_cal_target (four measured shifts; its default Gaussian PSF and a PSF that is not rank 1, --psf measured;
+    rgb_cal_target/run_sr.py:128-166, 171-192, 340-373) for its 50 and for 80 iterations on a frame of several windows, against the oracle
+    at the north-star tolerances."""
     from oracle import sr_oracle as O
     S.set_precision("f32")
-    f, shifts, psf, (h, w) = 2, synth.MEASURED_4, synth.gaussian_psf(), (110, 150)
+    f, shifts, psf, (h, w) = 2, synth.MEASURED_4, _btile_psf(kind), (110, 150)
     O.set_threads(16)
     try:
         truth = synth.truth_image(h * f, w * f, seed=81)
@@ -1016,7 +1040,7 @@ def test_two_launch_window_kernels_80_iterations_and_full_size():
 # ---------------------------------------------------------------------------------------------------------
 # Round 4: REFERENCE-generated goldens for the window kernels (tools/make_golden.py --only-windows)
 # ---------------------------------------------------------------------------------------------------------
-WIN_RGB_PATH = {"g": "btile", "m": "fused"}  # the implementation each PSF of rgb_cal_target must reach in float32
+WIN_RGB_PATH = {"g": "btile", "m": "btile"}  # the implementation each PSF of rgb_cal_target must reach in float32
 
 
 @pytest.mark.parametrize("psf_tag", ["g", "m"])
@@ -1093,7 +1117,8 @@ def test_80_iterations_multi_tile(prec, cfg):
     finally:
         O.set_threads(1)
     hr, errs = S.ibp_batched(lr[None], shifts, psf, saa_o[None], f, 80, 0.5, flags=flags)
-    assert S.last_path() == ("atile" if (want == "mosaic" and prec == "f32") else want)  # (float32, rank-1 PSF: the two-launch window kernels)
+    # (float32: the two-launch window kernels for the rank-1 PSF at a common fraction, the path-B window kernels' 7 x 7 form on measured shifts)
+    assert S.last_path() == (("atile" if want == "mosaic" else "btile") if prec == "f32" else want)
     close(hr[0].cpu().numpy(), hr_o, IBP_TOL[prec])
     np.testing.assert_allclose(errs[0].cpu().numpy(), err_o, rtol=ERR_RTOL[prec])
 
