@@ -69,7 +69,7 @@ struct BArgs {
     float kby[8], kbx[8];  // forward blur (correlation) weights, times kq
     float kty[8], ktx[8];  // backward blur (flipped kernel) weights
     float k2f[56], k2b[56];  // a PSF that is not rank 1: the 7 x 7 correlation weights of the forward (times kq^2) / backward blur, row v of the
-                             // PSF as eight words in blur2d_rows' pairing: K[v][0], [1] | [4], [5] | [6], [2] | [3], 0
+                             // PSF as eight words in blur2d_rows' pairing: K[v][0], [1] | [4], [5] | [6], [2] | [3], 0 (5 x 5: [2], [1] | [4], [5] | [3])
     BFrame fr[MAXF];
 };
 
@@ -239,69 +239,111 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
 __device__ __forceinline__ float dpp_up(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_dn(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false)); }
 
-// input row R of the block (R = -3 .. 66; a template recursion: `#pragma unroll` gave up part-way and indexed the registers dynamically).
-// e0 / e1: the edge columns of rows R and R + 1 (requested two rows ahead of their use: an LDS read right in front of its shifts cost
-// the LDS latency per row).
-template <int R> __device__ __forceinline__ float4 blur2d_edge(const float *eU, const float *eM, const float *eD)
+// Input rows R = -RAD .. 63 + RAD of the block, one step each (a template recursion: `#pragma unroll` gave up part-way and indexed the
+// registers dynamically).  The edge columns of a row are requested three steps ahead of their use.  RAD: the PSF's support is (2 RAD + 1)^2 -- 3 for a full 7 x 7; 2 when its outer ring is zero, which
+// is what the reference's measured PSF looks like (rgb_cal_target/run_sr.py:160-166: background subtracted, clipped at 0 -- a 5 x 5 core):
+// four shifts and 15 multiply-add instructions per row instead of six and 28.
+template <int R, int RAD> __device__ __forceinline__ float4 blur2d_edge(const float *eU, const float *eM, const float *eD)
 {
-    return *reinterpret_cast<const float4 *>(R < 0 ? eU + 8 * (64 + R) : (R < 64 ? eM + 8 * (R & 63) : eD + 8 * (R - 64)));
+    const float *p = R < 0 ? eU + 8 * (64 + R) : (R < 64 ? eM + 8 * (R & 63) : eD + 8 * (R - 64));
+    if constexpr (RAD == 3)
+        return *reinterpret_cast<const float4 *>(p);
+    const float2 v = *reinterpret_cast<const float2 *>(p);
+    return make_float4(v.x, v.y, 0.f, 0.f);
 }
-template <int R>
-__device__ __forceinline__ void blur2d_rows(float (&a)[64], v2f (&acc)[7], const float (&hl)[3], const float (&hr)[3], const float *eU, const float *eM,
-                                            const float *eD, const f8 (&kv)[7], float4 e, float4 e1)
+struct B2Row {  // an input row and its shifted copies: s[u] = the row shifted by u - 3 lanes (s[3] = the row itself)
+    float s[7];
+};
+template <int R, int RAD>
+__device__ __forceinline__ B2Row blur2d_shift(const float (&a)[64], const float (&hl)[3], const float (&hr)[3], float4 e)
 {
-    float4 e2 = e1;
-    if constexpr (R + 2 <= 66)
-        e2 = blur2d_edge<R + 2>(eU, eM, eD);
+    B2Row w;
     const float in = R < 0 ? hl[R < 0 ? R + 3 : 0] : (R < 64 ? a[R >= 0 && R < 64 ? R : 0] : hr[R >= 64 ? R - 64 : 0]);
-    const float s2 = dpp_up(in, e.x), s1 = dpp_up(s2, e.y), s0 = dpp_up(s1, e.z);
-    const float s4 = dpp_dn(in, e.x), s5 = dpp_dn(s4, e.y), s6 = dpp_dn(s5, e.z);
-    // (the pairs follow the registers the shifts leave their results in: the down chain overwrites the three words of the LDS read in
-    // place, its fourth word is where s2 goes)
-    const v2f p01 = {s0, s1}, p45 = {s4, s5}, p62 = {s6, s2};
-    // pair-major: the seven output rows' instructions of one pair are independent of each other (a dependent VALU instruction issues
-    // ~11 cycles behind its producer, and one or two waves per SIMD do not fill that gap)
+    w.s[3] = in;
+    w.s[2] = dpp_up(in, e.x), w.s[1] = dpp_up(w.s[2], e.y);
+    w.s[4] = dpp_dn(in, e.x), w.s[5] = dpp_dn(w.s[4], e.y);
+    w.s[0] = w.s[6] = 0.f;
+    if constexpr (RAD == 3)
+        w.s[0] = dpp_up(w.s[1], e.z), w.s[6] = dpp_dn(w.s[5], e.z);
+    return w;
+}
+// One step = the multiply-adds of input row R (its shifted copies `cur` were made a step earlier) + the shifts of row R + 1 + the LDS
+// read of row R + 3's edge columns + the last add of the output row that completed a step earlier.  Software-pipelined by hand: with
+// everything of a row in one step the wave ran the row's dependent chain (read -> shift -> shift -> shift -> 3 packed fmas -> fma ->
+// add, ~11 cycles a link, nothing to put between them) once per row: 150 cycles per row whatever the PSF's support (stamps: 10 K cycles
+// per blur, 5 x 5 and 7 x 7 alike).
+template <int R, int RAD>
+__device__ __forceinline__ void blur2d_rows(float (&a)[64], v2f (&acc)[7], const float (&hl)[3], const float (&hr)[3], const float *eU, const float *eM,
+                                            const float *eD, const f8 (&kv)[7], const B2Row cur, float4 e1, float4 e2)
+{
+    constexpr int NA = 2 * RAD + 1;  // output rows in flight
+    float4 e3 = e2;
+    if constexpr (R + 3 <= 63 + RAD)
+        e3 = blur2d_edge<R + 3, RAD>(eU, eM, eD);
+    if constexpr (R - 1 >= RAD) {  // output row R - 1 - RAD saw its last input row a step ago
+        const v2f A = acc[(R - 1 - RAD) % NA];
+        a[R - 1 - RAD] = A.x + A.y;
+        asm volatile("" : "+v"(a[R - 1 - RAD]));
+    }
+    B2Row nxt = cur;
+    if constexpr (R < 63 + RAD)
+        nxt = blur2d_shift<R + 1, RAD>(a, hl, hr, e1);
+    // (the pairs follow the registers the shifts leave their results in: the down chain overwrites the words of the LDS read in place;
+    // with RAD = 3 the read's fourth word is where s2 goes)
+    v2f pA, pB, pC = {0.f, 0.f};
+    if constexpr (RAD == 3)
+        pA = (v2f){cur.s[0], cur.s[1]}, pB = (v2f){cur.s[4], cur.s[5]}, pC = (v2f){cur.s[6], cur.s[2]};
+    else
+        pA = (v2f){cur.s[2], cur.s[1]}, pB = (v2f){cur.s[4], cur.s[5]};
+    // pair-major: the output rows' instructions of one pair are independent of each other
 #pragma unroll
     for (int q = 0; q < 4; q++) {
+        if (RAD == 2 && q == 2)
+            continue;
 #pragma unroll
-        for (int v = 0; v < 7; v++) {
+        for (int v = 3 - RAD; v <= 3 + RAD; v++) {
             const int o = R - v + 3;  // the output row this PSF row feeds
             if (o < 0 || o > 63)
                 continue;
             const f8 k = kv[v];
-            v2f &A = acc[(o + 7) % 7];
+            v2f &A = acc[(o + NA) % NA];
             if (q == 0) {
-                if (v == 0)  // the output's first input row
-                    A = (v2f){k[0], k[1]} * p01;
+                if (v == 3 - RAD)  // the output's first input row
+                    A = (v2f){k[0], k[1]} * pA;
                 else
-                    A = __builtin_elementwise_fma((v2f){k[0], k[1]}, p01, A);
+                    A = __builtin_elementwise_fma((v2f){k[0], k[1]}, pA, A);
             } else if (q == 1)
-                A = __builtin_elementwise_fma((v2f){k[2], k[3]}, p45, A);
+                A = __builtin_elementwise_fma((v2f){k[2], k[3]}, pB, A);
             else if (q == 2)
-                A = __builtin_elementwise_fma((v2f){k[4], k[5]}, p62, A);
+                A = __builtin_elementwise_fma((v2f){k[4], k[5]}, pC, A);
             else
-                A.x = fmaf(k[6], in, A.x);
+                A.x = fmaf(RAD == 3 ? k[6] : k[4], cur.s[3], A.x);
         }
     }
-    if constexpr (R >= 3) {  // output row R - 3 has seen its last input row
-        const v2f A = acc[(R - 3) % 7];
-        a[R - 3] = A.x + A.y;
-        asm volatile("" : "+v"(a[R - 3]));
-    }
-    // Row by row.  An opaque use of every partial sum right here: left alone the multiply-adds of an output row are SUNK to where the row is
-    // complete (six input rows later: 49 shifted copies live instead of 7, ~340 spilled registers), and the scheduler issues the LDS reads
+    // Step by step.  An opaque use of every partial sum right here: left alone the multiply-adds of an output row are SUNK to where the row
+    // is complete (six input rows later: 49 shifted copies live instead of 7, ~340 spilled registers), and the scheduler issues the LDS reads
     // and shifts of many rows up front.
 #pragma unroll
-    for (int v = 0; v < 7; v++) {
+    for (int v = 3 - RAD; v <= 3 + RAD; v++) {
         const int o = R - v + 3;
-        if (o >= 0 && o <= 63 && v < 6)
-            asm volatile("" : "+v"(acc[(o + 7) % 7]));
+        if (o >= 0 && o <= 63)
+            asm volatile("" : "+v"(acc[(o + NA) % NA]));
+    }
+    if constexpr (R < 63 + RAD) {
+#pragma unroll
+        for (int u = 3 - RAD; u <= 3 + RAD; u++)
+            asm volatile("" : "+v"(nxt.s[u]));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (R < 66)
-        blur2d_rows<R + 1>(a, acc, hl, hr, eU, eM, eD, kv, e1, e2);
+    if constexpr (R < 63 + RAD)
+        blur2d_rows<R + 1, RAD>(a, acc, hl, hr, eU, eM, eD, kv, nxt, e2, e3);
+    else {
+        const v2f A = acc[(R - RAD) % NA];
+        a[R - RAD] = A.x + A.y;
+    }
 }
 
+template <int RAD>
 __device__ __forceinline__ void blur2d_cross(float (&a)[64], bool sfirst, bool slast, bool ufirst, bool ulast, float *Xown, const float *Xup, const float *Xdn,
                                              const float *zero, int lane, const f8 (&kv)[7])
 {
@@ -311,14 +353,14 @@ __device__ __forceinline__ void blur2d_cross(float (&a)[64], bool sfirst, bool s
     Xown[SLOT_A + 192 + lane] = a[61];
     Xown[SLOT_A + 256 + lane] = a[62];
     Xown[SLOT_A + 320 + lane] = a[63];
-    if (lane < 3 || lane > 60) {  // row i: words 0..2 = columns 0, 1, 2; words 4..6 = columns 63, 62, 61 (the order a neighbour shifts them in)
+    if (lane < RAD || lane > 63 - RAD) {  // row i: words 0..2 = columns 0, 1, 2; words 4..6 = columns 63, 62, 61 (the order a neighbour shifts them in)
         float *pub = Xown + SLOT_C + (lane < 3 ? lane : 67 - lane);
 #pragma unroll
         for (int i = 0; i < 64; i++)
             pub[8 * i] = a[i];
     }
     __syncthreads();
-    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+    float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};  // rows -3, -2, -1 and 64, 65, 66
     if (!sfirst)
         hl[0] = Xup[SLOT_A + 192 + lane], hl[1] = Xup[SLOT_A + 256 + lane], hl[2] = Xup[SLOT_A + 320 + lane];
     if (!slast)
@@ -328,8 +370,9 @@ __device__ __forceinline__ void blur2d_cross(float (&a)[64], bool sfirst, bool s
     const float *eM = l0 ? (ufirst ? zero : Xown - XW + SLOT_C + 4) : (l63 && !ulast ? Xown + XW + SLOT_C : zero);
     const float *eU = l0 ? (ufirst || sfirst ? zero : Xup - XW + SLOT_C + 4) : (l63 && !ulast && !sfirst ? Xup + XW + SLOT_C : zero);
     const float *eD = l0 ? (ufirst || slast ? zero : Xdn - XW + SLOT_C + 4) : (l63 && !ulast && !slast ? Xdn + XW + SLOT_C : zero);
-    v2f acc[7];  // output rows r - 3 .. r + 3 of the current input row r, as pairs of partial sums: acc[o % 7]
-    blur2d_rows<-3>(a, acc, hl, hr, eU, eM, eD, kv, blur2d_edge<-3>(eU, eM, eD), blur2d_edge<-2>(eU, eM, eD));
+    v2f acc[7];  // output rows r - RAD .. r + RAD of the current input row r, as pairs of partial sums: acc[o % (2 RAD + 1)]
+    const B2Row first = blur2d_shift<-RAD, RAD>(a, hl, hr, blur2d_edge<-RAD, RAD>(eU, eM, eD));
+    blur2d_rows<-RAD, RAD>(a, acc, hl, hr, eU, eM, eD, kv, first, blur2d_edge<1 - RAD, RAD>(eU, eM, eD), blur2d_edge<2 - RAD, RAD>(eU, eM, eD));
 }
 
 // H-FIR of frame HALF of a pair with decimation: s[32 HALF + j] = sum_b w[b] c[2 j + PAR + b]
@@ -538,12 +581,13 @@ template <int NBY, int NBX> struct Geo {
 // =========================================================================================================================
 // forward: err[b, k, i, j] = lr - (F_k P pad B hr)[2 i, 2 j];  epart[b, window] = sum err^2 * scale.  grid (nwx, nwy, B)
 // =========================================================================================================================
-template <int NBY, int NBX, bool SEP>
+template <int NBY, int NBX, int PSF>  // PSF: 0 = rank 1 (7 + 7 taps); 2, 3 = the 2-D form with a support of 5 x 5 / 7 x 7
 __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bfwd(const float *__restrict__ S, const float *__restrict__ lr, float *__restrict__ err, BArgs A, const int *__restrict__ frtab,
                double *__restrict__ epart, double scale)
 {
     using L = Lds<NBY, NBX>;
+    constexpr bool SEP = PSF == 0;
     __shared__ __attribute__((aligned(16))) float lds[L::WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave / NBX, u = wave % NBX;
@@ -586,7 +630,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
 #pragma unroll
         for (int v = 0; v < 7; v++)
             kv[v] = ld8(A.k2f + 8 * v);
-        blur2d_cross(a, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
+        blur2d_cross<(PSF == 2 ? 2 : 3)>(a, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
     }
     SRX_PSTAMP(2);
     edge_replicate(a, Pb, H + SRX_NPAD - 1, R0y + 64 * NBY - 1 > H + SRX_NPAD - 1, edge + 64 * u + lane);
@@ -725,12 +769,13 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
 // backward: hr_out = clip(hr_in + step * B'( crop P ( sum_k F'_k pad U err_k ) ) / N) on the window's owned pixels.
 // grid (nwx, nwy, B).  The window (0, 0) of an item also sums the forward kernel's per-window MSE partials.
 // =========================================================================================================================
-template <int NBY, int NBX, bool SEP>
+template <int NBY, int NBX, int PSF>
 __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
     k_ibp_bbwd(const float *__restrict__ err, float *__restrict__ S, BArgs A, const int *__restrict__ frtab, const double *__restrict__ epart,
                double *__restrict__ errors, int errors_stride)
 {
     using L = Lds<NBY, NBX>;
+    constexpr bool SEP = PSF == 0;
     __shared__ __attribute__((aligned(16))) float lds[L::WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave / NBX, u = wave % NBX;
@@ -942,7 +987,7 @@ __global__ void __launch_bounds__(NBY *NBX * 64, SRX_BT_MINB)
 #pragma unroll
         for (int v = 0; v < 7; v++)
             kv[v] = ld8(A.k2b + 8 * v);
-        blur2d_cross(r, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
+        blur2d_cross<(PSF == 2 ? 2 : 3)>(r, s == 0, s == NBY - 1, u == 0, u == NBX - 1, Xown, Xup, Xdn, zero, lane, kv);
     }
     SRX_PSTAMP(21);
     {
@@ -1011,7 +1056,15 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
         A.kty[i] = kt.cy[i], A.ktx[i] = kt.cx[i];
     }
     const bool sep = kc.separable && kt.separable;
-    static const int pairing[8] = {0, 1, 4, 5, 6, 2, 3, -1};  // blur2d_rows: (S0, S1) (S4, S5) (S6, S2) packed, S3 alone
+    int rad = 0;  // support radius of the embedded 7 x 7 (the flipped kernel's is the same)
+    for (int v = 0; v < 7; v++)
+        for (int uu = 0; uu < 7; uu++)
+            if (kc.k[7 * v + uu] != 0.f || kt.k[7 * v + uu] != 0.f)
+                rad = std::max(rad, std::max(std::abs(v - 3), std::abs(uu - 3)));
+    const int psf_form = sep ? 0 : (rad <= 2 ? 2 : 3);
+    // blur2d_rows' pairing of the shifted copies: (S0, S1) (S4, S5) (S6, S2) packed, S3 alone; 5 x 5: (S2, S1) (S4, S5), S3
+    static const int pairing3[8] = {0, 1, 4, 5, 6, 2, 3, -1}, pairing2[8] = {2, 1, 4, 5, 3, -1, -1, -1};
+    const int *pairing = psf_form == 2 ? pairing2 : pairing3;
     for (int v = 0; v < 7; v++)
         for (int q = 0; q < 8; q++) {
             const int uu = pairing[q];
@@ -1051,13 +1104,18 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
     SRX_CHECK_LAUNCH();
     const dim3 grid(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
-        if (sep) {
-            SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX, true>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
-            SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX, true>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
-        } else {
-            SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX, false>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);
-            SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX, false>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter);
-        }
+#define SRX_BT_ITER(P_)                                                                                                                        \
+    do {                                                                                                                                       \
+        SRX_LAUNCH(KID_IBP_BFWD, (k_ibp_bfwd<NBY, NBX, P_>), grid, blk, 0, st, S, lr, err, A, frtab, errors ? epart : nullptr, scale);          \
+        SRX_LAUNCH(KID_IBP_BBWD, (k_ibp_bbwd<NBY, NBX, P_>), gridb, blk, 0, st, err, S, A, frtab, epart, errors ? errors + it : nullptr, n_iter); \
+    } while (0)
+        if (psf_form == 0)
+            SRX_BT_ITER(0);
+        else if (psf_form == 2)
+            SRX_BT_ITER(2);
+        else
+            SRX_BT_ITER(3);
+#undef SRX_BT_ITER
     }
     hipLaunchKernelGGL(k_btile_copy_out, cgrid, dim3(256), 0, st, S, H, W, H4, hr);
     SRX_CHECK_LAUNCH();

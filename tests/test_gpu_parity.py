@@ -844,12 +844,14 @@ BTILE_CFGS = {
     "tiny_asym": (synth.MEASURED_4, (20, 33), "asym"),
     "smallest_asym5": (synth.MEASURED_4, (16, 16), "asym5"),  # a 5 x 5 kernel embedded in the 7 x 7
     "meas4_gauss_as_7x7": (synth.MEASURED_4, (90, 140), "gauss7x7"),  # the Gaussian through the 7 x 7 form (SRX_FLAG_DIAG_NO_SEPARABLE)
+    "meas4_full7": (synth.MEASURED_4, (90, 140), "full7"),  # not rank 1 AND non-zero out to the 7 x 7's corners (the asymmetric ones have a 5 x 5 core)
 }
 
 
 def _btile_psf(kind):
     a = synth.asymmetric_psf()
-    return {"gauss": synth.gaussian_psf(), "gauss7x7": synth.gaussian_psf(), "asym": a, "asym5": a[1:6, 1:6] / a[1:6, 1:6].sum()}[kind]
+    return {"gauss": synth.gaussian_psf(), "gauss7x7": synth.gaussian_psf(), "asym": a, "asym5": a[1:6, 1:6] / a[1:6, 1:6].sum(),
+            "full7": 0.6 * synth.gaussian_psf() + 0.4 * a}[kind]
 
 
 @pytest.mark.parametrize("cfg", sorted(BTILE_CFGS))

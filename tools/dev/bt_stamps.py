@@ -7,7 +7,7 @@ import torch
 import sr_mi355x as S
 from sr_mi355x import _lib, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-f, shifts, psf = 2, synth.MEASURED_4, synth.gaussian_psf()
+f, shifts, psf = 2, synth.MEASURED_4, (synth.asymmetric_psf() if len(sys.argv) > 2 and sys.argv[2] == "asym" else synth.gaussian_psf())
 lr = torch.round(torch.rand((B, 4, 768, 1024), device="cuda") * 255)
 saa = S.shift_and_add_batched(lr, shifts, f)
 S.ibp_batched(lr, shifts, psf, saa, f, 3, 0.5)
