@@ -122,26 +122,19 @@ struct Plan {
 
 static inline bool plan(int H, int W, Plan &pl)
 {
-    Plan best;
-    double bt = 1e30;
-    for (int nsx = 4; nsx >= ((call_flags() & SRX_FLAG_DIAG_WIDE_WINDOWS) ? 4 : 3); nsx--) {
-        Plan p;
-        p.nsx = nsx;
-        if (!plan_axis_tiles(H, RY, ALIGN_Y, p.ty) || !plan_axis_tiles(W, 64 * nsx, ALIGN_X, p.tx))
-            continue;
-        // One window per compute unit at a time, modelled for ONE frame (a batch must give every item the result it would get alone, bit
-        // for bit, so the plan may not depend on the batch).  Measured on 3072 x 4096 (round 3): a round of 12-wave windows 37 us, of
-        // 16-wave windows 55 us; eight frames 592 against 574 us per iteration -- what the narrow shape loses on a batch is 3 %.
-        const long tiles = (long)p.ty.n * p.tx.n;
-        if (tiles > 1024)
-            continue;
-        const double t = (double)((tiles + 255) / 256) * (nsx == 4 ? 1.0 : 0.68);
-        if (t < bt)
-            bt = t, best = p;
-    }
-    if (bt > 1e29)
+    // 4 x 3 waves (256 x 192 windows, 128 x 192 owned in the interior) unless the caller asks for the 16-wave shape.  Round 3 chose between
+    // the two by a cost model of ONE frame (a round of 12-wave windows 37 us, of 16-wave windows 55 us on 3072 x 4096; eight frames 592
+    // against 574 us per iteration: what the narrow shape loses on a batch is 3 %).  Round 4 drops the choice: the 16-wave kernel has 128
+    // registers per lane and does not fit them (44 spilled registers with 0/1 count masks, 142 with a count plane -- after this round's
+    // fixes; 72 / 246 before), the 12-wave one has 168 and is clean, and every width the wide shape takes the narrow one takes too.  The
+    // plan depends on the shape only, so a batch gives every item the bits it gets alone.
+    Plan p;
+    p.nsx = (call_flags() & SRX_FLAG_DIAG_WIDE_WINDOWS) ? 4 : 3;
+    if (!plan_axis_tiles(H, RY, ALIGN_Y, p.ty) || !plan_axis_tiles(W, 64 * p.nsx, ALIGN_X, p.tx))
         return false;
-    pl = best;
+    if ((long)p.ty.n * p.tx.n > 1024)
+        return false;
+    pl = p;
     return true;
 }
 
@@ -523,53 +516,91 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
             unsigned long long cm = cmask;
             asm volatile("" : "+s"(cm));
             float gn[3] = {0.f, 0.f, 0.f};
-            if (m8) {
-                float cq[4] = {0.f, 0.f, 0.f, 0.f};
+            // The operands arrive EIGHT columns at a time, one batch in flight behind the one being used.  Every batch's address passes through
+            // an asm that also takes the last G value of the batch before (and clobbers memory): these loads are pure reads whose addresses do
+            // not depend on the data, and left alone the compiler issues all 64 columns' worth above the loop (64 - 128 registers in flight beside
+            // the plane: round 3's <false, 4> form spilled 246 registers, 456 bytes of scratch per lane).
+            float dep = 0.f;
+            constexpr int NB = (NSX == 4 || !C01) ? 4 : 8;  // (the 16-wave window has 128 registers per lane, the 12-wave one 168; a count plane is a second operand)
+            auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int j0, float(&v)[NB]) {
+                int off = tbl;
+                asm volatile("" : "+s"(off), "+v"(dep)::"memory");
 #pragma unroll
-                for (int j = 0; j < 64; j++) {
-                    const float mv = (float)((m8w[j >> 2] >> (8 * (j & 3))) & 255u);
-                    float g, w;
-                    if (C01) {
-                        const bool on = (cm >> j) & 1ull;
-                        g = on ? fmaf(-crow, r[j], mv) : 0.f;
-                        w = 1.f;
-                    } else {
-                        if ((j & 3) == 0)
-                            ld4(rsC, vrow, tbl + (j >> 2) * H * 16, cq[0], cq[1], cq[2], cq[3]);
-                        const float cv = cq[j & 3];
-                        g = fmaf(-cv, r[j], mv);
-                        w = mosaic::rcp_count(cv);
+                for (int q = 0; q < NB / 4; q++)
+                    ld4(rs, vrow, off + ((j0 >> 2) + q) * H * 16, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            };
+            if (m8) {
+                float cqa[NB], cqb[NB];
+                if (!C01)
+                    fetch(rsC, 0, cqa);
+#pragma unroll
+                for (int j0 = 0; j0 < 64; j0 += NB) {
+                    float(&cq)[NB] = (j0 & NB) ? cqb : cqa;
+                    float(&cn)[NB] = (j0 & NB) ? cqa : cqb;
+                    if (!C01 && j0 + NB < 64)
+                        fetch(rsC, j0 + NB, cn);
+#pragma unroll
+                    for (int jj = 0; jj < NB; jj++) {
+                        const int j = j0 + jj;
+                        const float mv = (float)((m8w[j >> 2] >> (8 * (j & 3))) & 255u);
+                        float g, w;
+                        if (C01) {
+                            const bool on = (cm >> j) & 1ull;
+                            g = on ? fmaf(-crow, r[j], mv) : 0.f;
+                            w = 1.f;
+                        } else {
+                            const float cv = cq[jj];
+                            g = fmaf(-cv, r[j], mv);
+                            w = mosaic::rcp_count(cv);
+                        }
+                        const float g2 = g * g * w;
+                        sqg[j >> 4] += g2;
+                        if (j < 3)
+                            gn[j] = g2;
+                        r[j] = g;
                     }
-                    const float g2 = g * g * w;
-                    sqg[j >> 4] += g2;
-                    if (j < 3)
-                        gn[j] = g2;
-                    r[j] = g;
+                    if (!C01) {
+                        // (an opaque use of the batch's results: left alone their arithmetic is SUNK below the loop, to where G is first read,
+                        // and every batch's operands stay live until then)
+#pragma unroll
+                        for (int jj = 0; jj < NB; jj++)
+                            asm volatile("" : "+v"(r[j0 + jj]));
+                        dep = r[j0 + NB - 1];
+                        __builtin_amdgcn_sched_barrier(0);  // (... and in front of the next batch's loads)
+                    }
                 }
             } else {
+                float mva[NB], mvb[NB], cva[NB], cvb[NB];
+                fetch(rsM, 0, mva);
+                if (!C01)
+                    fetch(rsC, 0, cva);
 #pragma unroll
-                for (int j0 = 0; j0 < 64; j0 += 16) {
-                    float mv[16], cv[16];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        ld4(rsM, vrow, tbl + ((j0 >> 2) + q) * H * 16, mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
-                        if (C01) {
-#pragma unroll
-                            for (int c = 0; c < 4; c++)
-                                cv[4 * q + c] = ((cm >> (j0 + 4 * q + c)) & 1ull) ? crow : 0.f;
-                        } else {
-                            ld4(rsC, vrow, tbl + ((j0 >> 2) + q) * H * 16, cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
-                        }
+                for (int j0 = 0; j0 < 64; j0 += NB) {
+                    float(&mv)[NB] = (j0 & NB) ? mvb : mva;
+                    float(&mn)[NB] = (j0 & NB) ? mva : mvb;
+                    float(&cv)[NB] = (j0 & NB) ? cvb : cva;
+                    float(&cn)[NB] = (j0 & NB) ? cva : cvb;
+                    if (j0 + NB < 64) {
+                        fetch(rsM, j0 + NB, mn);
+                        if (!C01)
+                            fetch(rsC, j0 + NB, cn);
                     }
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const float g = fmaf(-cv[j], r[j0 + j], mv[j]);
-                        const float g2 = g * g * (C01 ? 1.f : mosaic::rcp_count(cv[j]));
-                        sqg[j0 >> 4] += g2;
-                        if (j0 + j < 3)
-                            gn[j0 + j] = g2;
-                        r[j0 + j] = g;
+                    for (int jj = 0; jj < NB; jj++) {
+                        const int j = j0 + jj;
+                        const float c = C01 ? (((cm >> j) & 1ull) ? crow : 0.f) : cv[jj];
+                        const float g = fmaf(-c, r[j], mv[jj]);
+                        const float g2 = g * g * (C01 ? 1.f : mosaic::rcp_count(c));
+                        sqg[j >> 4] += g2;
+                        if (j < 3)
+                            gn[j] = g2;
+                        r[j] = g;
                     }
+#pragma unroll
+                    for (int jj = 0; jj < NB; jj++)
+                        asm volatile("" : "+v"(r[j0 + jj]));
+                    dep = r[j0 + NB - 1];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (u == 0)  // the first nbx columns of a left window are near band: not part of the far-field sum
@@ -589,12 +620,18 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
 #pragma unroll
                 for (int j0 = 0; j0 < 64; j0 += 8) {
                     float v[8];
+                    // (an opaque offset that also takes the batch before's last value, and a memory clobber: these LDS reads depend on
+                    // nothing, and left alone all 64 are issued up front -- 64 registers beside the plane's 64, in a 128-register kernel)
+                    int o = j0;
+                    asm volatile("" : "+v"(o), "+v"(r[j0 > 0 ? j0 - 1 : 0])::"memory");
 #pragma unroll
                     for (int j = 0; j < 8; j++)
-                        v[j] = src[j0 + j];
+                        v[j] = src[o + j];
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
+                    for (int j = 0; j < 8; j++) {
                         r[j0 + j] = rownear ? v[j] : r[j0 + j];
+                        asm volatile("" : "+v"(r[j0 + j]));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (u == 0 && exx && rownear)
