@@ -13,6 +13,7 @@
 #include "srx_ctile.hpp"
 #include "srx_btile.hpp"
 #include "srx_atile.hpp"
+#include "srx_metrics.hpp"
 
 using namespace srx;
 
@@ -494,6 +495,51 @@ int srx_interleave4_u8(const uint8_t *frames, int B, int h, int w, uint8_t *out,
     SRX_CHECK_LAUNCH();
     return SRX_OK;
 }
+
+size_t srx_metrics_workspace_bytes(int B, int H, int W, int nbin)
+{
+    const size_t a = metrics::moments_ws(B > 0 ? B : 1), b = metrics::rows_ws(H > 0 ? H : 1, nbin > 0 ? nbin : 1),
+                 c = 2 * align_up((size_t)(H > 0 ? H : 1) * (W > 0 ? W : 1) * sizeof(double));
+    return std::max(a, std::max(b, c));
+}
+
+int srx_edge_magnitude_f64(const double *roi, int H, int W, double sigma, double *mag, void *ws, size_t wsb, srx_stream_t s)
+{
+    return metrics::edge_magnitude(roi, H, W, sigma, mag, ws, wsb, hs(s));
+}
+
+int srx_edge_dist_range(int H, int W, double m, double b, double norm, int rows_are_x, double *out, srx_stream_t s)
+{
+    if (!out || H <= 0 || W <= 0 || !(norm > 0.0) || (size_t)H * W > (1u << 24))
+        return SRX_E_INVALID;
+    metrics::EdgeLine e{m, b, norm, 0.0, 0.25, rows_are_x, 1};
+    hipLaunchKernelGGL(metrics::k_edge_dist_range, dim3(1), dim3(256), 0, hs(s), H, W, e, out);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+#define SRX_DEFINE_METRICS(SFX, T)                                                                                                            \
+    int srx_pair_moments_##SFX(const T *ref, const T *test, int B, int H, int W, int border, double *out, void *ws, size_t wsb, srx_stream_t s) \
+    {                                                                                                                                         \
+        return metrics::pair_moments<T>(ref, test, B, H, W, border, out, ws, wsb, hs(s));                                                      \
+    }                                                                                                                                         \
+    int srx_local_contrast_##SFX(const T *prof, int B, int n, int window, T *out, srx_stream_t s)                                             \
+    {                                                                                                                                         \
+        return metrics::local_contrast<T>(prof, B, n, window, out, hs(s));                                                                     \
+    }                                                                                                                                         \
+    int srx_ring_sums_##SFX(const T *img, int H, int W, double cy, double cx, int nbin, double *out, void *ws, size_t wsb, srx_stream_t s)      \
+    {                                                                                                                                         \
+        return metrics::ring_sums<T>(img, H, W, cy, cx, nbin, out, ws, wsb, hs(s));                                                            \
+    }                                                                                                                                         \
+    int srx_spot_moments_##SFX(const T *img, int H, int W, double *out, srx_stream_t s) { return metrics::spot_moments<T>(img, H, W, out, hs(s)); } \
+    int srx_edge_bins_##SFX(const T *roi, int H, int W, double m, double b, double norm, int rows_are_x, double lo, double bw, int nbin,       \
+                            double *out, void *ws, size_t wsb, srx_stream_t s)                                                                \
+    {                                                                                                                                         \
+        metrics::EdgeLine e{m, b, norm, lo, bw, rows_are_x, nbin};                                                                             \
+        return metrics::edge_bins<T>(roi, H, W, e, out, ws, wsb, hs(s));                                                                       \
+    }
+SRX_DEFINE_METRICS(f32, float)
+SRX_DEFINE_METRICS(f64, double)
 
 #define SRX_DEFINE(SFX, T)                                                                                             \
     int srx_blur_##SFX(const T *img, int B, int H, int W, const double *k, int kh, int kw, T *out, srx_stream_t s)      \

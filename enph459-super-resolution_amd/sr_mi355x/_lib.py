@@ -35,6 +35,11 @@ _TYPED = {
     "srx_mean_frames_{T}": (_I, [_P, _I, _I, _Z, _P, _P]),
     "srx_u8_to_{T}": (_I, [_P, _Z, _P, _P]),
     "srx_quantize_u8_{T}": (_I, [_P, _Z, _P, _P]),
+    "srx_pair_moments_{T}": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "srx_local_contrast_{T}": (_I, [_P, _I, _I, _I, _P, _P]),
+    "srx_ring_sums_{T}": (_I, [_P, _I, _I, _D, _D, _I, _P, _P, _Z, _P]),
+    "srx_spot_moments_{T}": (_I, [_P, _I, _I, _P, _P]),
+    "srx_edge_bins_{T}": (_I, [_P, _I, _I, _D, _D, _D, _I, _D, _D, _I, _P, _P, _Z, _P]),
 }
 _PLAIN = {
     "srx_version": (_I, []),
@@ -52,6 +57,9 @@ _PLAIN = {
     "srx_saa_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "srx_ibp_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _U]),
     "srx_ibp_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _HD, _HD, _I, _I, _U]),
+    "srx_metrics_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "srx_edge_magnitude_f64": (_I, [_P, _I, _I, _D, _P, _P, _Z, _P]),
+    "srx_edge_dist_range": (_I, [_I, _I, _D, _D, _D, _I, _P, _P]),
 }
 
 

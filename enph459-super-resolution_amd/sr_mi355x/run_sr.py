@@ -55,8 +55,9 @@ def main(argv=None):
     sessions = session.discover_sessions(args.data_dir, args.kind)
     print(f"Found {len(sessions)} session(s):\n" + "\n".join(f"  {os.path.basename(s)}" for s in sessions))
     t0 = time.time()
-    metrics_cb = session.write_metrics if (args.metrics and args.kind == "mono_cal_target") else None
-    session.process_sessions(sessions, psf, args.output_dir, args.kind, rank=rank, world=world, on_written=metrics_cb,
+    # --metrics: from the device tensors the PNGs were quantised from (session.write_metrics_device), not from the files
+    metrics_cb = session.write_metrics_device if (args.metrics and args.kind == "mono_cal_target") else None
+    session.process_sessions(sessions, psf, args.output_dir, args.kind, rank=rank, world=world, on_images=metrics_cb,
                              row_bands=args.row_bands and world > 1)
     if dist is not None:
         dist.barrier()

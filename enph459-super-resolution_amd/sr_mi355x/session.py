@@ -301,7 +301,7 @@ def _save_outputs(out_dir, images, errors, lr_name, extra=None):
 
 
 def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None, verbose=True, batch_reps=True, loaded=None, flush=True,
-                    row_bands=False):
+                    row_bands=False, on_images=None):
     """Counterpart of process_session / process_combo.  Returns the list of output directories written
     (empty if everything was already done).  batch_reps: the reps of a barcode session that are still to do go through the
     library in one B = reps call (reconstruct_batch) instead of one call per rep; `loaded`: frames already decoded by a
@@ -330,6 +330,8 @@ def process_session(session_dir, psf_kernel, output_base, kind=None, n_iter=None
         if images["SAA_IBP"] is None:  # row-band mode, not rank 0: the assembled image lives on rank 0
             return written
         _save_outputs(out_dir, images, errors, lr_name, extra)
+        if on_images:  # (the device tensors the PNGs were quantised from: metrics without reading the files back)
+            on_images(out_dir, images)
         if flush:
             flush_writes()
         say(f"  Output: {out_dir}")
@@ -368,7 +370,8 @@ def load_session(session_dir, kind):
     return load_corner_reps(session_dir, kind == "rgb_barcodes")
 
 
-def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None, row_bands=False):
+def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbose=True, rank=0, world=1, on_written=None, row_bands=False,
+                     on_images=None):
     """The reference's outer loop (mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301) over the sessions this
     rank owns (session i -> rank i mod world, parallel.map_sharded: independent items, no data-path collective), with the PNG
     decode and upload of session k + 1 overlapped with the device work of session k.  -> output directories written: by every
@@ -395,7 +398,7 @@ def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbo
         count[0] += 1
         say(f"\n[rank {rank}: {count[0]}/{len(owned)}] {os.path.basename(sessions[i])}")
         out = process_session(sessions[i], psf_kernel, output_base, kind=kind, n_iter=n_iter, verbose=verbose, loaded=loaded,
-                              flush=on_written is not None, row_bands=row_bands)
+                              flush=on_written is not None, row_bands=row_bands, on_images=on_images)
         if on_written:
             for d in out:
                 on_written(d)
@@ -413,6 +416,22 @@ def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbo
     if per_session is None:  # not rank 0 of a sharded job
         return []
     return [d for out in per_session for d in out]
+
+
+def write_metrics_device(out_dir, images, factor=UPSAMPLE_FACTOR):
+    """metrics.json for one mono_cal_target output directory from the DEVICE tensors of the reconstruction (process_session's
+    on_images hook): the notebook's summary (analysis.ipynb cells 3-10) on the values the PNGs hold -- clamped and truncated to 0..255,
+    run_sr.py:303 -- with every pass over a frame or an ROI in libsrx (sr_mi355x/metrics_device.py), plus the full-frame PSNR figures
+    of SAA+IBP against the two baselines (one fused reduction over two 12.6 MP device images each; the affine-fit form is the vendor
+    GUI's comparison, XPR_Software.py:735-745, 1215-1256)."""
+    from . import metrics_device as md
+    q = {n: api.u8_to_float(api.quantize_u8(images[n]), precision="f32") for n in ("native_2x", "SAA", "SAA_IBP")}  # 0..255 integers, on the device
+    rep = md.cal_target_report(q, factor=factor)
+    rep["psnr_db"] = {f"SAA_IBP_vs_{n}": {"plain": md.psnr(q[n], q["SAA_IBP"]), "affine_fit": float(md.psnr_affine(q[n], q["SAA_IBP"]))}
+                      for n in ("native_2x", "SAA")}
+    with open(os.path.join(out_dir, "metrics.json"), "w") as fp:
+        json.dump(rep, fp, indent=2)
+    return rep
 
 
 def write_metrics(out_dir, factor=UPSAMPLE_FACTOR):

@@ -182,6 +182,38 @@ int srx_quantize_u8_f64(const double *in, size_t n, uint8_t *out, srx_stream_t s
  * (tx, ty) = (0,0), (0,+1), (-1,+1), (-1,0) HR pixels with cv2.BORDER_REFLECT_101, the four planes summed as uint8. */
 int srx_interleave4_u8(const uint8_t *frames, int B, int h, int w, uint8_t *out, srx_stream_t stream);
 
+/* ---- quality metrics that consume the reconstructions, on DEVICE images ----
+ * The reference computes these in its notebook / calibration scripts from the PNGs it wrote (mono_cal_target/analysis.ipynb cells 4, 7, 10;
+ * data_collection/psf_mtf_utils.py:67-95; the vendor GUI's PSNR, opt_materials/software/XPR_Software.py:735-745, 1215-1256).  These entry points
+ * are the parts that are work on a frame or an ROI; sr_mi355x/metrics.py keeps the few-thousand-operation host parts (percentile, line fits,
+ * 72-sample FFT, the 7-parameter fit, compute_mtf's 256^2 FFT).  All results are float64 DEVICE arrays; every sum is a fixed-order reduction
+ * (bit-identical run to run).  Workspace: srx_metrics_workspace_bytes(B, H, W, nbin) covers every call below at those sizes.
+ *   pair_moments : out[b] = {n, sum t, sum r, sum t^2, sum t r, sum r^2, sum (r - t)^2} over rows / columns [border, size - border) of
+ *                  ref / test [B, H, W]: PSNR = 10 log10(peak^2 n / out[6]); the affine-fit PSNR follows from the other five.
+ *   local_contrast: (max - min) / (max + min + 1e-9) of profile[i - w/2 : i + w/2], 0 within w/2 of either end.  [B, n] -> [B, n]
+ *   ring_sums    : ring k = pixels whose distance to (cy, cx) truncates to k: out = {sum[nbin], count[nbin]}   (radial_average)
+ *   spot_moments : out = {max, sum p, sum p y, sum p x} over the pixels with p > 0.1 max                       (subpixel_centre)
+ *   edge_magnitude: Sobel magnitude of the Gaussian(sigma)-smoothed ROI, scipy.ndimage 'reflect' boundaries; float64 [H, W] -> [H, W]
+ *   edge_dist_range / edge_bins: every ROI pixel projected on the normal of the line v = m u + b ((u, v) = (row, col) if rows_are_x else
+ *                  (col, row)): min / max of the distances in (-8, 10); sums and counts per 1/4-px bin [lo + i bw, lo + (i + 1) bw). */
+size_t srx_metrics_workspace_bytes(int B, int H, int W, int nbin);
+int srx_pair_moments_f32(const float *ref, const float *test, int B, int H, int W, int border, double *out, void *ws, size_t ws_bytes,
+                         srx_stream_t stream);
+int srx_pair_moments_f64(const double *ref, const double *test, int B, int H, int W, int border, double *out, void *ws, size_t ws_bytes,
+                         srx_stream_t stream);
+int srx_local_contrast_f32(const float *profile, int B, int n, int window, float *out, srx_stream_t stream);
+int srx_local_contrast_f64(const double *profile, int B, int n, int window, double *out, srx_stream_t stream);
+int srx_ring_sums_f32(const float *img, int H, int W, double cy, double cx, int nbin, double *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+int srx_ring_sums_f64(const double *img, int H, int W, double cy, double cx, int nbin, double *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+int srx_spot_moments_f32(const float *img, int H, int W, double *out, srx_stream_t stream);
+int srx_spot_moments_f64(const double *img, int H, int W, double *out, srx_stream_t stream);
+int srx_edge_magnitude_f64(const double *roi, int H, int W, double sigma, double *mag, void *ws, size_t ws_bytes, srx_stream_t stream);
+int srx_edge_dist_range(int H, int W, double m, double b, double norm, int rows_are_x, double *out, srx_stream_t stream);
+int srx_edge_bins_f32(const float *roi, int H, int W, double m, double b, double norm, int rows_are_x, double lo, double bw, int nbin,
+                      double *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+int srx_edge_bins_f64(const double *roi, int H, int W, double m, double b, double norm, int rows_are_x, double lo, double bw, int nbin,
+                      double *out, void *ws, size_t ws_bytes, srx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,3 +188,38 @@ def test_run_sr_row_bands_two_ranks_on_one_gpu(tmp_path, g_real):
     m1, m2 = (json.load(open(d / "convergence.json"))["ibp_mse"] for d in (d1, d2))
     np.testing.assert_allclose(m2, m1, rtol=2e-5)
     assert os.path.exists(d2 / "done.flag")
+
+
+def test_metrics_json_from_device_tensors_equals_the_file_based_report(tmp_path):
+    """`run_sr --metrics`: metrics.json is written from the device tensors the PNGs were quantised from (session.write_metrics_device:
+    every pass over a frame / ROI in libsrx) and equals the notebook summary computed on the host from the PNGs themselves
+    (session.write_metrics, analysis.ipynb cells 3-10), on a full-size synthetic mono_cal_target session (1536 x 2048 -> 3072 x 4096)."""
+    from sr_mi355x import metrics as M
+    S.set_precision("f32")
+    h, w = 1536, 2048
+    yy, xx = np.mgrid[0:h, 0:w]
+    (r0, r1), (c0, c1) = M.ROI2_LR
+    d = (xx - 0.5 * (c0 + c1)) * np.cos(0.35) + (yy - 0.5 * (r0 + r1)) * np.sin(0.35)
+    img = 40.0 + 170.0 / (1.0 + np.exp(-(np.abs(d) - 12.0) / 0.4))      # a dark diagonal line through ROI 2 (sharp: MTF50 inside the sampled band)
+    c = M.ROI1_COL_LR
+    img[:, c - 20:c + 20] = (128.0 + 90.0 * np.sign(np.sin(yy / 2.3)))[:, c - 20:c + 20]  # horizontal bars through ROI 1
+    rng = np.random.default_rng(12)
+    sess = tmp_path / "data" / "cal_target_full"
+    sess.mkdir(parents=True)
+    for k, (fname, _) in enumerate(session.IMAGE_SHIFTS):
+        Image.fromarray(np.clip(np.roll(img, (k % 2, k // 2), axis=(0, 1)) + rng.normal(0, 1.0, img.shape), 0, 255).astype(np.uint8)).save(sess / fname)
+    got = {}
+    written = session.process_session(str(sess), S.make_gaussian_psf(), str(tmp_path / "results"), n_iter=5, verbose=False,
+                                      on_images=lambda out_dir, images: got.update(session.write_metrics_device(out_dir, images)))
+    dev = json.load(open(os.path.join(written[0], "metrics.json")))
+    assert dev == json.loads(json.dumps(got))
+    host = session.write_metrics(written[0])  # from the PNGs, host numpy
+    for title in ("native_2x", "SAA", "SAA_IBP"):
+        for k, v in host[title].items():
+            same_nan = np.isnan(v) and np.isnan(dev[title][k])  # (an MTF that never falls through 0.1 in the sampled band: nan on both sides)
+            assert same_nan or abs(v - dev[title][k]) <= 1e-6 * max(1.0, abs(v)), (title, k, v, dev[title][k])
+        assert np.isfinite(host[title]["mtf50"]) and host[title]["mean_contrast"] > 0.1
+    q = {n: np.array(Image.open(os.path.join(written[0], n + ".png"))) for n in ("native_2x", "SAA", "SAA_IBP")}
+    for n in ("native_2x", "SAA"):
+        assert abs(dev["psnr_db"][f"SAA_IBP_vs_{n}"]["affine_fit"] - M.psnr_affine(q[n], q["SAA_IBP"])) < 1e-6
+        assert abs(dev["psnr_db"][f"SAA_IBP_vs_{n}"]["plain"] - M.psnr(q[n], q["SAA_IBP"])) < 1e-9
