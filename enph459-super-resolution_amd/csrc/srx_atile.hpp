@@ -525,8 +525,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     const dim3 gridf(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {
         SRX_LAUNCH(KID_IBP_AFWD, (k_ibp_afwd<NBY, NBX>), gridf, blk, 0, st, S, MCq, G, Yb, A, errors ? epart : nullptr, scale);
-        hipLaunchKernelGGL(k_atile_near, dim3(A.nnear, B), dim3(256), 0, st, Mg, Mu, ncu, nyx, NS, NB, Yb, G, A, errors ? epart : nullptr, scale);
-        SRX_CHECK_LAUNCH();
+        SRX_LAUNCH(KID_ATILE_NEAR, k_atile_near, dim3(A.nnear, B), dim3(256), 0, st, Mg, Mu, ncu, nyx, NS, NB, Yb, G, A, errors ? epart : nullptr, scale);
         SRX_LAUNCH(KID_IBP_ABWD, (k_ibp_abwd<NBY, NBX>), gridb, blk, 0, st, G, S, A, epart, Vtot, scale, errors ? errors + it : nullptr, n_iter);
     }
     hipLaunchKernelGGL(k_atile_copy_out, cgrid, cblk, 0, st, S, H, W, W4, hr);

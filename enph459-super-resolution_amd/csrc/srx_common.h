@@ -92,6 +92,9 @@ enum KernelId {
     KID_IBP_BBWD,
     KID_IBP_AFWD,
     KID_IBP_ABWD,
+    KID_PATCH_BUILD,
+    KID_PATCH_FLAGS,
+    KID_ATILE_NEAR,
     KID_COUNT
 };
 

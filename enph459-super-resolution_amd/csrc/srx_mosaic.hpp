@@ -67,11 +67,22 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
                    double scale, double *errors, hipStream_t st);
 }  // namespace atile
+namespace mosaic {
+struct MTap;
+}
 namespace patch {
+// a full phase grid: the patch path builds its operand planes straight from the LR frames (no M / C / Mu planes of the whole batch)
+static inline bool builds_itself(const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, int N, int f);
+struct Source {  // what that build reads
+    const float *lr;
+    int h, w;
+    const mosaic::MTap *tabY, *tabX;  // [N][Hg], [N][Wg]
+    double *Vtot;
+};
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int n_iter, double step, double scale,
-                   double *errors, hipStream_t st);
+                   double *errors, hipStream_t st, const Source &src);
 }  // namespace patch
 namespace mosaic {
 
@@ -1209,7 +1220,13 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     SRX_CHECK_LAUNCH();
     if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
-    if (B >= 8)
+    // (a batch of patches on a full phase grid: the patch path reads the LR frames itself, srx_patch.hpp's k_patch_build -- the M plane
+    // of 1024 patches is 328 MB written here and read back once by k_patch_prep)
+    bool own_build = false;
+    if constexpr (sizeof(T) == 4)
+        own_build = impl == IMPL_PATCH && patch::builds_itself(py, px, N, f);
+    if (own_build) {
+    } else if (B >= 8)
         SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h,
                    w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
     else
@@ -1224,9 +1241,11 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         return ctile::iterate<T>(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors, st);
     if constexpr (sizeof(T) == 4) {
         // a 256 x 256 patch fits one compute unit: the whole iteration in one launch, no intermediate planes (srx_patch.hpp)
-        if (impl == IMPL_PATCH)
+        if (impl == IMPL_PATCH) {
+            const patch::Source src{lr, h, w, tabY, tabX, Vtot};
             return patch::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale,
-                                  errors, st);
+                                  errors, st, src);
+        }
         // integer HR shifts on a large frame: the whole iteration in one launch over CU-resident 64 x 256 tiles (srx_ztile.hpp)
         if (impl == IMPL_DTILE)
             return dtile::iterate(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors,

@@ -253,6 +253,141 @@ __global__ void __launch_bounds__(256)
     Mn[(size_t)b * NN_PAD + t] = make_float2(Mg[((size_t)b * Wg + ngy + 13) * Wg + ngx + 13], Mu[(size_t)b * NB + ni]);
 }
 
+// ---- the same tables straight from the LR frames, for full phase grids (c01: every far-field HR pixel holds at most one sample) ------
+// k_mosaic_build + k_patch_prep write and re-read an M plane of the whole batch (1024 patches: 328 MB out, 328 MB in, on top of the 268 MB
+// of LR frames, with a gather that fetches 64 useful bytes per load instruction): 0.57 ms of a 12.6 ms C2 step.  On a full phase grid
+// row gy of M is the INTERLEAVE of one LR row of the f frames of its row class -- M[gy][gx] = lr[K[cy(gy)][cx(gx)]][iy(gy)][jx(gx)],
+// depth-to-space -- so the operand planes follow from the LR frames in one pass: a lane takes a column QUAD (for x4 the four frames of
+// the row class at one LR column: four coalesced 256-byte reads per wave and row), a 16-row band goes through LDS so that the
+// transposed planes leave in 256-byte runs.  The byte / float form is chosen BEFORE the build (k_patch_flags: all samples of the patch
+// are integers in [0, 255]) so that only the plane the iteration kernel will read is written: 64 KB instead of 320 KB per patch.
+struct AxisMap {       // per natural coordinate g of a patch: the class of the frames that land there and the LR index they bring
+    signed char cls[PN];   // -1: no frame (C = 0)
+    unsigned char idx[PN];
+};
+struct BuildMaps {
+    AxisMap y, x;
+    signed char frame[4][4];  // frame of (row class, column class)
+    int nby, nbx;
+};
+__global__ void k_patch_maps(BuildMaps v, BuildMaps *dst)  // (a lane-indexed by-value argument compiles to a scalar-load loop over the lanes)
+{
+    const int *s = reinterpret_cast<const int *>(&v);
+    int *d = reinterpret_cast<int *>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(BuildMaps) / 4); i += blockDim.x)
+        d[i] = s[i];
+}
+// m8[b] (preset non-zero) cleared when a sample of patch b is not an integer in [0, 255].  grid (ceil(n / 4096), B), block 256
+__global__ void __launch_bounds__(256) k_patch_flags(const float *__restrict__ lr, size_t n, int *__restrict__ m8)
+{
+    const int b = blockIdx.y;
+    const float4 *p = reinterpret_cast<const float4 *>(lr + (size_t)b * n);
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const size_t i = ((size_t)blockIdx.x * 4 + q) * 256 + threadIdx.x;
+        if (4 * i + 3 < n) {
+            const float4 v = p[i];
+            ok = ok && v.x == rintf(v.x) && v.x >= 0.f && v.x <= 255.f && v.y == rintf(v.y) && v.y >= 0.f && v.y <= 255.f &&
+                 v.z == rintf(v.z) && v.z >= 0.f && v.z <= 255.f && v.w == rintf(v.w) && v.w >= 0.f && v.w <= 255.f;
+        } else {
+            for (size_t j = 4 * i; j < n && j < 4 * i + 4; j++) {
+                const float x = lr[(size_t)b * n + j];
+                ok = ok && x == rintf(x) && x >= 0.f && x <= 255.f;
+            }
+        }
+    }
+    if (__syncthreads_or(!ok) && threadIdx.x == 0)
+        atomicAnd(&m8[b], 0);
+}
+// grid (PN / 16 bands, B), block 256: wave w takes rows w, w + 4, ... of the band, lane = column quad
+__global__ void __launch_bounds__(256)
+    k_patch_build(const float *__restrict__ lr, int N, int h, int w, const BuildMaps *__restrict__ maps, const int *__restrict__ m8,
+                  float *__restrict__ Mt, unsigned *__restrict__ Mt8)
+{
+    __shared__ float4 tile[64][17];  // [column quad][row of the band] (+1: the write-out walks a quad's rows)
+    const int b = blockIdx.y, gy0 = blockIdx.x * 16, cq = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool bytes = __builtin_amdgcn_readfirstlane(m8[b]) != 0;
+    const float *src = lr + (size_t)b * N * h * w;
+    int cx[4], jx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int gx = 4 * cq + c;
+        cx[c] = gx < maps->nbx ? -1 : maps->x.cls[gx];  // near-band columns: the kernel takes them from the near-band lists
+        jx[c] = maps->x.idx[gx];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int r = wv + 4 * m, gy = gy0 + r;
+        const int cy = gy < maps->nby ? -1 : (int)maps->y.cls[gy], iy = maps->y.idx[gy];  // wave-uniform
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cy >= 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (cx[c] >= 0)
+                    v[c] = src[((size_t)maps->frame[cy][cx[c]] * h + iy) * w + jx[c]];
+        }
+        tile[cq][r] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if (bytes) {
+        // Mt8[b][cq >> 2][gy][cq & 3]: one word per (quad, row); consecutive threads = the four quads of a group, then the rows
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int u = threadIdx.x + 256 * n, sub = u & 3, r = (u >> 2) & 15, grp = u >> 6, q = 4 * grp + sub;
+            const float4 t = tile[q][r];
+            const unsigned wd = (unsigned)t.x | (unsigned)t.y << 8 | (unsigned)t.z << 16 | (unsigned)t.w << 24;
+            Mt8[(size_t)b * (PN / 4) * PN + ((size_t)grp * PN + gy0 + r) * 4 + sub] = wd;
+        }
+    } else {
+        // Mt[b][cq][gy][4]: 16 bytes per (quad, row); consecutive threads = the rows of a quad
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int u = threadIdx.x + 256 * n, r = u & 15, q = u >> 4;
+            reinterpret_cast<float4 *>(Mt)[((size_t)b * (PN / 4) + q) * PN + gy0 + r] = tile[q][r];
+        }
+    }
+}
+// (M, Mu) of the near-band pixels of every patch from the LR frames (k_mosaic_build's sums, on the near band only), and the patch's
+// share of the within-pixel scatter V (zero on a full phase grid; kept for the definition's sake).  grid (ceil(nn / 256), B)
+__global__ void __launch_bounds__(256)
+    k_patch_near_build(const float *__restrict__ lr, int N, int h, int w, const mosaic::MTap *__restrict__ tabY, const mosaic::MTap *__restrict__ tabX,
+                       int Hg, int Wg, int Dy, int Dx, int exy, int exx, int nby, int nbx, int nn, float2 *__restrict__ Mn, double *__restrict__ Vtot)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    double var = 0.0;
+    if (t < nn) {
+        int ngy, ngx, dst;
+        near_coords(t, exy, exx, nby, nbx, ngy, ngx, dst);
+        const int p = ngy + 13, q = ngx + 13;
+        const float *src = lr + (size_t)b * N * h * w;
+        double M = 0.0, S1 = 0.0, S2 = 0.0;
+        int cu = 0;
+        for (int k = 0; k < N; k++) {
+            const mosaic::MTap ty = tabY[(size_t)k * Hg + p], tx = tabX[(size_t)k * Wg + q];
+            if (ty.i < 0 || tx.i < 0)
+                continue;
+            const double lv = (double)src[((size_t)k * h + ty.i) * w + tx.i];
+            M += lv;
+            if (ty.rho == p - Dy && tx.rho == q - Dx)
+                S1 += lv, S2 += lv * lv, cu++;
+        }
+        Mn[(size_t)b * NN_PAD + t] = make_float2((float)M, (float)S1);
+        if (cu > 1)
+            var = S2 - S1 * S1 / (double)cu;
+    }
+    __shared__ double part[4];
+    const double ws = wave_sum(var);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sacc = part[0] + part[1] + part[2] + part[3];
+        if (sacc != 0.0)
+            atomicAdd(&Vtot[b], sacc);
+    }
+}
+
 // 16 bytes per lane through a buffer descriptor: the parked state travels as four rows per instruction (a CU issues a vector
 // memory instruction every ~9 cycles whatever its width -- 12 descriptor loads took a wave 1.7 K cycles to issue -- so the 64 + 64
 // one-word stores and loads that parked and re-read the state were a quarter of the iteration's critical path)
@@ -1049,10 +1184,48 @@ static inline bool c01_masks(const mosaic::AxisPlan &py, const mosaic::AxisPlan 
 }
 
 // device memory of the patch path's tables, carved from the caller's workspace by mosaic::ibp
+// class tables of a full phase grid: which frames land on natural coordinate g along one axis (their class) and the LR index they bring
+static inline bool axis_map(const mosaic::AxisPlan &pl, int N, int f, AxisMap &am, int cls_of_frame[SRX_MAX_FRAMES], int &ncls)
+{
+    int nv[SRX_MAX_FRAMES];
+    ncls = 0;
+    for (int k = 0; k < N; k++) {
+        int c = -1;
+        for (int j = 0; j < ncls; j++)
+            if (nv[j] == pl.n[k])
+                c = j;
+        if (c < 0) {
+            if (ncls == 4)
+                return false;
+            c = ncls, nv[ncls++] = pl.n[k];
+        }
+        cls_of_frame[k] = c;
+    }
+    for (int g = 0; g < PN; g++) {
+        am.cls[g] = -1, am.idx[g] = 0;
+        for (int c = 0; c < ncls; c++) {
+            const int uu = g + nv[c];  // k_build_mtaps: u = p + n - 13 with p = g + 13
+            if (uu >= 0 && uu <= PN - 1 && uu % f == 0)
+                am.cls[g] = (signed char)c, am.idx[g] = (unsigned char)(uu / f);
+        }
+    }
+    return true;
+}
+
+static inline bool builds_itself(const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, int N, int f)
+{
+    unsigned long long ry[4], rx[4];
+    if ((call_flags() & SRX_FLAG_DIAG_NO_ZERO_FUSE) || !c01_masks(py, px, N, f, ry, rx) || PN / f > 255)
+        return false;  // (SRX_FLAG_DIAG_NO_ZERO_FUSE: the cross-check -- the tables through the batch's M / C / Mu planes, as round 3 built them)
+    BuildMaps bm;
+    int cy[SRX_MAX_FRAMES], cx[SRX_MAX_FRAMES], ny, nx;
+    return axis_map(py, N, f, bm.y, cy, ny) && axis_map(px, N, f, bm.x, cx, nx) && ny * nx == N;
+}
+
 static inline size_t tabs_bytes(int B, int N)
 {
     const size_t ngrp = ((size_t)N + 3) / 4;
-    return align_up((size_t)B * PN * PN * 4) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * 4) +
+    return align_up(sizeof(BuildMaps)) + align_up((size_t)B * PN * PN * 4) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * 4) +
            align_up((size_t)NN_PAD * 8) + align_up(ngrp * NN_PAD * 8) + align_up((size_t)B * NN_PAD * 8) + align_up(2 * sizeof(AxisW));
 }
 
@@ -1060,9 +1233,10 @@ static inline size_t tabs_bytes(int B, int N)
 static int iterate(const float *hr_init, float *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
                    const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int n_iter, double step, double scale,
-                   double *errors, hipStream_t st)
+                   double *errors, hipStream_t st, const Source &src)
 {
     const int Hg = PN + 27, Wg = PN + 27, ngrp = NS / 4;
+    BuildMaps *maps = ar.take<BuildMaps>(1);
     float *Mt = ar.take<float>((size_t)B * PN * PN);
     unsigned *Mt8 = ar.take<unsigned>((size_t)B * (PN / 4) * PN);
     int *m8 = ar.take<int>(B);
@@ -1085,14 +1259,37 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     pa.c01 = c01_masks(py, px, N, f, pa.ry, pa.rx) ? 1 : 0;
     if (hipMemsetAsync(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
-    hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
-    SRX_CHECK_LAUNCH();
+    const bool own = builds_itself(py, px, N, f);  // (what mosaic::ibp asked before it decided not to build M / C / Mu)
+    if (own) {
+        BuildMaps bm;
+        int cy[SRX_MAX_FRAMES], cx[SRX_MAX_FRAMES], ny, nx;
+        axis_map(py, N, f, bm.y, cy, ny);
+        axis_map(px, N, f, bm.x, cx, nx);
+        for (int a = 0; a < 4; a++)
+            for (int c = 0; c < 4; c++)
+                bm.frame[a][c] = 0;
+        for (int q = 0; q < N; q++)
+            bm.frame[cy[q]][cx[q]] = (signed char)q;
+        bm.nby = pa.y.nb, bm.nbx = pa.x.nb;
+        hipLaunchKernelGGL(k_patch_maps, dim3(1), dim3(256), 0, st, bm, maps);
+        SRX_CHECK_LAUNCH();
+        const size_t n = (size_t)N * src.h * src.w;
+        SRX_LAUNCH(KID_PATCH_FLAGS, k_patch_flags, dim3((unsigned)((n + 4095) / 4096), B), dim3(256), 0, st, src.lr, n, m8);
+        SRX_LAUNCH(KID_PATCH_BUILD, k_patch_build, dim3(PN / 16, B), dim3(256), 0, st, src.lr, N, src.h, src.w, maps, m8, Mt, Mt8);
+    } else {
+        hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
+        SRX_CHECK_LAUNCH();
+    }
     if (pa.nn > 0) {
         hipLaunchKernelGGL(k_patch_near_tab, dim3(cdiv(pa.nn, 256)), dim3(256), 0, st, ncu, nyx, NS, py.PB, px.PB, pa.y.ex, pa.x.ex, pa.y.nb,
                            pa.x.nb, pa.y.E, pa.x.E, pa.nn, nrec, nent);
         SRX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_patch_near_m, dim3(cdiv(pa.nn, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, pa.y.ex, pa.x.ex, pa.y.nb,
-                           pa.x.nb, pa.nn, Mn);
+        if (own)
+            hipLaunchKernelGGL(k_patch_near_build, dim3(cdiv(pa.nn, 256), B), dim3(256), 0, st, src.lr, N, src.h, src.w, src.tabY, src.tabX, Hg, Wg,
+                               py.D, px.D, pa.y.ex, pa.x.ex, pa.y.nb, pa.x.nb, pa.nn, Mn, src.Vtot);
+        else
+            hipLaunchKernelGGL(k_patch_near_m, dim3(cdiv(pa.nn, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, pa.y.ex, pa.x.ex, pa.y.nb,
+                               pa.x.nb, pa.nn, Mn);
         SRX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);

@@ -714,6 +714,25 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert S.last_path() == "mosaic"
 
 
+def test_patch_tables_from_the_lr_frames_equal_the_plane_route():
+    """Round 4: on a full phase grid the patch path builds its operand planes straight from the LR frames (k_patch_flags, k_patch_build,
+    k_patch_near_build) instead of through the batch's M / C / Mu planes (k_mosaic_build, k_patch_prep, k_patch_near_m: kept, on request,
+    as the cross-check).  Same tables, so the same bits: integer frames (byte mosaic), non-integer frames (float mosaic), a mixed batch,
+    a 3 x 4 sub-grid, x2."""
+    S.set_precision("f32")
+    psf = synth.gaussian_psf()
+    for f, shifts in ((4, synth.phase_shifts(4)), (4, [s for s in synth.phase_shifts(4) if s[0] > -0.3]), (2, synth.phase_shifts(2))):
+        _, lr, saa = _patch_case(f, shifts, 3)
+        lr_d, saa_d = torch.from_numpy(lr).cuda().float(), torch.from_numpy(saa).cuda().float()
+        lr_d[1] = lr_d[1] * 0.75 + 0.3  # item 1: non-integer samples
+        lr_d[2, 3, 5, 7] += 0.5         # item 2: ONE non-integer sample
+        a, ea = S.ibp_batched(lr_d, shifts, psf, saa_d, f, 7, 0.5)
+        assert S.last_path() == "patch"
+        b, eb = S.ibp_batched(lr_d, shifts, psf, saa_d, f, 7, 0.5, flags=S.FLAG_DIAG_NO_ZERO_FUSE)
+        assert S.last_path() == "patch"
+        assert torch.equal(a, b) and torch.equal(ea, eb)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # k_ibp_dtile: frames with a common sub-pixel fraction > 0 on overlapping register-resident windows (srx_dtile.hpp)
 # ---------------------------------------------------------------------------------------------------------
