@@ -366,9 +366,153 @@ static int saa_dispatch(const T *lr, int B, int N, int h, int w, const double *s
 }
 
 // ---------------------------------------------------------------------------------------
+// plans: the per-call tables built ONCE, the iterations in several runs, rows of the state readable / replaceable in between
+// (what a row band of a larger image needs: sr_mi355x/rowband.py).  A plan keeps device state in the caller's workspace and a
+// small host record; the frames and the workspace must stay alive until the plan is destroyed.
+// ---------------------------------------------------------------------------------------
+struct srx_plan_s {
+    int eb, B, N, h, w, H, W, f, kh, kw, tr_lo, tr_hi;
+    double step;
+    unsigned flags;
+    double sh[2 * SRX_MAX_FRAMES], k[SRX_MAX_KERNEL_TAPS];
+    const void *lr;
+    bool z;               // k_ibp_ztile with hoisted tables (float32, integer HR shifts, frames of at least 128 x 128)
+    ztile::State zs;
+    void *hr;             // otherwise: the state as a plain [B, H, W] plane at the head of the workspace; every run is a whole srx_ibp call
+    void *ws_rest;
+    size_t wsb_rest;
+    const char *path;
+};
+
+template <typename T>
+static int plan_create(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const T *hr_init, int H, int W, int f,
+                       double step, int tr_lo, int tr_hi, void *ws, size_t wsb, hipStream_t st, unsigned flags, srx_plan_s **out)
+{
+    if (!out || !basic_ibp_args_ok(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, 0, ws) || tr_lo < 0 || tr_hi > H || tr_lo > tr_hi)
+        return SRX_E_INVALID;
+    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || B > SRX_MAX_BATCH_PER_LAUNCH)
+        return SRX_E_UNSUPPORTED;
+    srx_plan_s *p = new srx_plan_s();
+    p->eb = (int)sizeof(T), p->B = B, p->N = N, p->h = h, p->w = w, p->H = H, p->W = W, p->f = f, p->kh = kh, p->kw = kw, p->tr_lo = tr_lo, p->tr_hi = tr_hi;
+    p->step = step, p->flags = flags, p->lr = lr, p->z = false, p->hr = nullptr, p->ws_rest = nullptr, p->wsb_rest = 0, p->path = "none";
+    std::memcpy(p->sh, sh, sizeof(double) * 2 * N);
+    std::memcpy(p->k, k, sizeof(double) * kh * kw);
+    Arena ar(ws, wsb);
+    int rc = SRX_OK;
+    bool z = false;
+    if constexpr (sizeof(T) == 4) {
+        z = !(flags & (SRX_FLAG_COMPOSED | SRX_FLAG_PER_FRAME)) && fused::ibp_eligible(N, h, w, sh, kh, kw, H, W, f) &&
+            mosaic::eligible(N, h, w, sh, kh, kw, H, W, f) && mosaic::choose_impl(4, N, H, W, sh, k, kh, kw, f) == mosaic::IMPL_ZTILE;
+        if (z) {
+            mosaic::Common<float> c;
+            rc = mosaic::common_prep<float>(c, mosaic::IMPL_ZTILE, lr, B, N, h, w, sh, k, kh, kw, H, W, f, ar, st, tr_lo, tr_hi);
+            if (rc == SRX_OK)
+                rc = ztile::setup(p->zs, hr_init, B, N, c.py, c.px, c.kc, c.kt, c.Mg, c.Cg, c.Mu, c.ncu, c.nyx, c.NS, c.NB, c.Vtot, ar, H, W, step,
+                                  1.0 / ((double)h * (double)w) / (double)N, tr_lo, tr_hi, st);
+            p->z = true, p->path = "ztile";
+        }
+    }
+    if (!z) {
+        T *hr = ar.take<T>((size_t)B * H * W);
+        if (!ar.ok)
+            rc = SRX_E_WORKSPACE;
+        else if (hipMemcpyAsync(hr, hr_init, (size_t)B * H * W * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = SRX_E_HIP;
+        p->hr = hr, p->ws_rest = ar.ok ? (char *)ws + ar.off : nullptr, p->wsb_rest = ar.ok ? wsb - ar.off : 0, p->path = "call per run";
+    }
+    if (rc != SRX_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return SRX_OK;
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_rows_copy(const T *__restrict__ src, T *__restrict__ dst, int H, int W, int y0, int rows, int to_plane)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W)
+        return;
+    const size_t ip = ((size_t)b * H + y0 + y) * W + x, ib = ((size_t)b * rows + y) * W + x;
+    if (to_plane)
+        dst[ip] = src[ib];
+    else
+        dst[ib] = src[ip];
+}
+
+template <typename T> static int plan_rows(srx_plan_s *p, int y0, int y1, T *buf, bool set, hipStream_t st)
+{
+    if (!p || !buf || p->eb != (int)sizeof(T) || y0 < 0 || y1 > p->H || y0 >= y1)
+        return SRX_E_INVALID;
+    const int rows = y1 - y0;
+    if (rows > 65535)
+        return SRX_E_UNSUPPORTED;
+    if (p->z) {
+        if constexpr (sizeof(T) == 4)
+            return set ? ztile::rows_in(p->zs, y0, rows, buf, st) : ztile::rows_out(p->zs, y0, rows, buf, st);
+        return SRX_E_INVALID;
+    }
+    T *hr = (T *)p->hr;
+    hipLaunchKernelGGL(k_rows_copy<T>, dim3(cdiv(p->W, 256), rows, p->B), dim3(256), 0, st, set ? (const T *)buf : (const T *)hr, set ? hr : buf, p->H, p->W, y0, rows,
+                       set ? 1 : 0);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // extern "C"
 // ---------------------------------------------------------------------------------------
 extern "C" {
+
+size_t srx_ibp_plan_workspace_bytes(int eb, int B, int N, int h, int w, int H, int W, int f, unsigned flags)
+{
+    return align_up((size_t)(B > 0 ? B : 1) * H * W * eb) + srx_ibp_workspace_bytes(eb, B, N, h, w, H, W, f, flags);
+}
+
+int srx_ibp_plan_create_f32(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
+                            int W, int f, double step, int tr_lo, int tr_hi, void *ws, size_t wsb, srx_stream_t s, unsigned flags, srx_plan_t **plan)
+{
+    CallFlags cf(flags);
+    return plan_create<float>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, step, tr_lo, tr_hi, ws, wsb, hs(s), flags, plan);
+}
+int srx_ibp_plan_create_f64(const double *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const double *hr_init, int H,
+                            int W, int f, double step, int tr_lo, int tr_hi, void *ws, size_t wsb, srx_stream_t s, unsigned flags, srx_plan_t **plan)
+{
+    CallFlags cf(flags);
+    return plan_create<double>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, step, tr_lo, tr_hi, ws, wsb, hs(s), flags, plan);
+}
+
+int srx_ibp_plan_run(srx_plan_t *p, int n_iter, double *errors, srx_stream_t s)
+{
+    if (!p || n_iter < 0)
+        return SRX_E_INVALID;
+    if (n_iter == 0)
+        return SRX_OK;
+    CallFlags cf(p->flags);
+    if (p->z)
+        return ztile::run(p->zs, n_iter, errors, hs(s));
+    if (errors && (p->tr_lo != 0 || p->tr_hi != p->H))
+        return SRX_E_UNSUPPORTED;  // a row range for the trace exists where the tables are hoisted (the float32 integer-shift frame kernel)
+    if (p->eb == 4)
+        return ibp_dispatch<float>((const float *)p->lr, p->B, p->N, p->h, p->w, p->sh, p->k, p->kh, p->kw, (const float *)p->hr, p->H, p->W, p->f, n_iter,
+                                   p->step, (float *)p->hr, errors, p->ws_rest, p->wsb_rest, hs(s), p->flags);
+    return ibp_dispatch<double>((const double *)p->lr, p->B, p->N, p->h, p->w, p->sh, p->k, p->kh, p->kw, (const double *)p->hr, p->H, p->W, p->f, n_iter,
+                                p->step, (double *)p->hr, errors, p->ws_rest, p->wsb_rest, hs(s), p->flags);
+}
+
+int srx_ibp_plan_get_rows_f32(srx_plan_t *p, int row_lo, int row_hi, float *dst, srx_stream_t s) { return plan_rows<float>(p, row_lo, row_hi, dst, false, hs(s)); }
+int srx_ibp_plan_set_rows_f32(srx_plan_t *p, int row_lo, int row_hi, const float *src, srx_stream_t s)
+{
+    return plan_rows<float>(p, row_lo, row_hi, const_cast<float *>(src), true, hs(s));
+}
+int srx_ibp_plan_get_rows_f64(srx_plan_t *p, int row_lo, int row_hi, double *dst, srx_stream_t s) { return plan_rows<double>(p, row_lo, row_hi, dst, false, hs(s)); }
+int srx_ibp_plan_set_rows_f64(srx_plan_t *p, int row_lo, int row_hi, const double *src, srx_stream_t s)
+{
+    return plan_rows<double>(p, row_lo, row_hi, const_cast<double *>(src), true, hs(s));
+}
+const char *srx_ibp_plan_path(srx_plan_t *p) { return p ? p->path : "none"; }
+int srx_ibp_plan_supports_trace_rows(srx_plan_t *p) { return p && p->z ? 1 : 0; }
+void srx_ibp_plan_destroy(srx_plan_t *p) { delete p; }
 
 int srx_version(void) { return 100; }
 

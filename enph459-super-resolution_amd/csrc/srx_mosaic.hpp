@@ -199,7 +199,7 @@ template <typename T, int IB, int PXT>
 __global__ void __launch_bounds__(256)
     k_mosaic_build(const T *__restrict__ lr, int B, int N, int h, int w, const MTap *__restrict__ tabY,
                    const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
-                   T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot)
+                   T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot, int tr_lo, int tr_hi)
 {
     __shared__ double part[4][IB];
     const int q0 = blockIdx.x * 64 * PXT + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b0 = blockIdx.z * IB;
@@ -268,7 +268,8 @@ __global__ void __launch_bounds__(256)
                 Mg[((size_t)(b0 + i) * Hg + pu) * Wg + q] = (T)M[c][i];
                 if (nearpx)
                     Mu[(size_t)(b0 + i) * NB + ni] = (T)S1[c][i];
-                if (Cu[c] > 1)
+                // (the trace's row range: a pixel counts where its clamped natural row lies in [tr_lo, tr_hi) -- all rows for a whole image)
+                if (Cu[c] > 1 && min(max(pu - 13, 0), Hg - 28) >= tr_lo && min(max(pu - 13, 0), Hg - 28) < tr_hi)
                     var[i] += S2[c][i] - S1[c][i] * S1[c][i] / (double)Cu[c];
             }
         }
@@ -1157,39 +1158,43 @@ static inline size_t ibp_ws_for(int eb, int B, int N, int H, int W, const double
     return ws_common(eb, B, N, H, W) + ws_impl(choose_impl(eb, N, H, W, sh, k, kh, kw, f), eb, B, N, H, W);
 }
 
+// What every implementation of formulation A shares, built once per call (or once per plan): the index maps, the LR mosaic M, the count
+// map C, the near band's counted sums Mu and lists, the constant part V of the MSE trace.
+template <typename T> struct Common {
+    AxisPlan py, px;
+    Kernel7<T> kc, kt;
+    MosaicArgs<T> ma;
+    T *Mg, *Cg, *Mu;
+    MTap *tabY, *tabX;
+    double *Vtot;
+    int *ncu, *nyx;
+    int NB, NS, Hg, Wg;
+    bool sep, zero, own_build;
+};
+
 template <typename T>
-static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
-               const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
-               size_t wsb, hipStream_t st, const char **took)
+static int common_prep(Common<T> &c, Impl impl, const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, int H, int W,
+                       int f, Arena &ar, hipStream_t st, int tr_lo, int tr_hi)
 {
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
-    AxisPlan py, px;
+    AxisPlan &py = c.py, &px = c.px;
     if (!plan_axis(N, sh, 0, f, py) || !plan_axis(N, sh, 1, f, px))
         return SRX_E_UNSUPPORTED;
-    const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
-    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : impl == IMPL_ATILE ? "atile" : "mosaic";  // what srx_last_path() reports: the branch taken
-    Arena ar(ws, wsb);
     const int NB = py.PB * Wg + (Hg - py.PB) * px.PB;  // pixels of the near band
     const int NS = (N + 3) & ~3;                        // slots per near-band pixel
-    T *Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = ar.take<T>((size_t)Hg * Wg);
-    T *Mu = ar.take<T>((size_t)B * NB);
-    MTap *tabY = ar.take<MTap>((size_t)N * Hg), *tabX = ar.take<MTap>((size_t)N * Wg);
-    double *Vtot = ar.take<double>(B);
-    int *ncu = ar.take<int>(NB), *nyx = ar.take<int>((size_t)NB * NS);
-    T *pad = nullptr, *G = nullptr;
-    double *epart = nullptr;
-    if (impl == IMPL_TILES) {
-        pad = ar.take<T>((size_t)B * Hp * Wp);
-        G = ar.take<T>((size_t)B * Hg * Wg);
-        epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
-    }
+    c.NB = NB, c.NS = NS, c.Hg = Hg, c.Wg = Wg;
+    T *Mg = c.Mg = ar.take<T>((size_t)B * Hg * Wg), *Cg = c.Cg = ar.take<T>((size_t)Hg * Wg);
+    T *Mu = c.Mu = ar.take<T>((size_t)B * NB);
+    MTap *tabY = c.tabY = ar.take<MTap>((size_t)N * Hg), *tabX = c.tabX = ar.take<MTap>((size_t)N * Wg);
+    double *Vtot = c.Vtot = ar.take<double>(B);
+    int *ncu = c.ncu = ar.take<int>(NB), *nyx = c.nyx = ar.take<int>((size_t)NB * NS);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     AxisDev dy, dx;
     dy.E = py.E, dy.D = py.D, dx.E = px.E, dx.D = px.D;
     for (int q = 0; q < SRX_MAX_FRAMES; q++)
         dy.n[q] = q < N ? py.n[q] : 0, dx.n[q] = q < N ? px.n[q] : 0;
-    MosaicArgs<T> ma;
+    MosaicArgs<T> &ma = c.ma;
     ma.Dy = py.D, ma.Dx = px.D, ma.PBy = py.PB, ma.PBx = px.PB, ma.RSy = py.RS, ma.RSx = px.RS;
     double wv[4];
     fused::host_weights(py.zero ? 0.0 : 1.0 - py.delta, wv);
@@ -1204,15 +1209,9 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     fused::host_weights(px.delta, wv);
     for (int i = 0; i < 4; i++)
         ma.wbx[i] = (T)wv[i];
-    Kernel7<T> kc, kt;
-    fused::make_kernel7<T>(k, kh, kw, false, kc);
-    fused::make_kernel7<T>(k, kh, kw, true, kt);
-    const bool sep = kc.separable && kt.separable, zero = py.zero && px.zero;
-    const size_t P = (size_t)B * H * W;
-    if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return SRX_E_HIP;
-    if (n_iter == 0)
-        return SRX_OK;
+    fused::make_kernel7<T>(k, kh, kw, false, c.kc);
+    fused::make_kernel7<T>(k, kh, kw, true, c.kt);
+    c.sep = c.kc.separable && c.kt.separable, c.zero = py.zero && px.zero;
     // ---- once per call: index maps, LR mosaic, count map, constant part of the MSE trace ----
     hipLaunchKernelGGL(k_build_mtaps, dim3(cdiv(Hg, 64), N), dim3(64), 0, st, tabY, Hg, H, f, dy);
     SRX_CHECK_LAUNCH();
@@ -1222,19 +1221,60 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
         return SRX_E_HIP;
     // (a batch of patches on a full phase grid: the patch path reads the LR frames itself, srx_patch.hpp's k_patch_build -- the M plane
     // of 1024 patches is 328 MB written here and read back once by k_patch_prep)
-    bool own_build = false;
+    c.own_build = false;
     if constexpr (sizeof(T) == 4)
-        own_build = impl == IMPL_PATCH && patch::builds_itself(py, px, N, f);
-    if (own_build) {
+        c.own_build = impl == IMPL_PATCH && patch::builds_itself(py, px, N, f);
+    if (c.own_build) {
     } else if (B >= 8)
         SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h,
-                   w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+                   w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot, tr_lo, tr_hi);
     else
         SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1, 4>), dim3(cdiv(Wg, 256), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w,
-                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot);
+                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot, tr_lo, tr_hi);
     hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+template <typename T>
+static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw,
+               const T *hr_init, int H, int W, int f, int n_iter, double step, T *hr, double *errors, void *ws,
+               size_t wsb, hipStream_t st, const char **took)
+{
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
+    const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : impl == IMPL_ATILE ? "atile" : "mosaic";  // what srx_last_path() reports: the branch taken
+    const size_t P = (size_t)B * H * W;
+    if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SRX_E_HIP;
+    if (n_iter == 0)
+        return SRX_OK;
+    Arena ar(ws, wsb);
+    Common<T> c;
+    {
+        const int rc = common_prep<T>(c, impl, lr, B, N, h, w, sh, k, kh, kw, H, W, f, ar, st, 0, H);
+        if (rc != SRX_OK)
+            return rc;
+    }
+    const AxisPlan &py = c.py, &px = c.px;
+    const Kernel7<T> &kc = c.kc, &kt = c.kt;
+    const MosaicArgs<T> &ma = c.ma;
+    T *Mg = c.Mg, *Cg = c.Cg, *Mu = c.Mu;
+    MTap *tabY = c.tabY, *tabX = c.tabX;
+    double *Vtot = c.Vtot;
+    int *ncu = c.ncu, *nyx = c.nyx;
+    const int NB = c.NB, NS = c.NS;
+    const bool sep = c.sep, zero = c.zero;
+    T *pad = nullptr, *G = nullptr;
+    double *epart = nullptr;
+    if (impl == IMPL_TILES) {
+        pad = ar.take<T>((size_t)B * Hp * Wp);
+        G = ar.take<T>((size_t)B * Hg * Wg);
+        epart = ar.take<double>((size_t)B * cdiv(Hg, 32) * cdiv(Wg, 32));  // per-tile MSE partial sums of one iteration
+        if (!ar.ok)
+            return SRX_E_WORKSPACE;
+    }
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     // integer HR shifts on a large frame, rows along the registers and columns along the lanes (float64; float32 on request)
     if (impl == IMPL_CTILE)

@@ -76,6 +76,8 @@ struct ZArgs {
     int WT, LN, TOPN;        // near-band enumeration: top band [exy + nby][WT], then left band [H - nby][LN]
     int ngrp;                // groups of 4 list entries per near-band pixel
     float sn;                // step / N
+    int tr_lo, tr_hi;        // the MSE trace counts the samples whose (clamped) natural row lies in [tr_lo, tr_hi): [0, H) for a whole image, a
+                             // rank's own rows when the image is one row band of a larger one (srx_ibp_plan_*, sr_mi355x/rowband.py)
 };
 
 struct ZTabs {
@@ -162,17 +164,18 @@ __device__ __forceinline__ size_t state_off(int b, int row, int col, int HP, int
 {
     return (size_t)b * (HP + 2) * WP + ((size_t)(row >> 1) * WP + col) * 2 + (row & 1);
 }
-__global__ void __launch_bounds__(256) k_ztile_copy_in(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
+// (image rows [y0, y0 + rows) of the plane <-> a packed [B][rows][W] buffer: the whole image, or the halo rows of a row band)
+__global__ void __launch_bounds__(256) k_ztile_copy_in(const float *__restrict__ src, int rows, int W, int HP, int WP, float *__restrict__ dst, int y0)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x < W)
-        dst[state_off(b, y + HALO, x + HALO, HP, WP)] = src[((size_t)b * H + y) * W + x];
+        dst[state_off(b, y0 + y + HALO, x + HALO, HP, WP)] = src[((size_t)b * rows + y) * W + x];
 }
-__global__ void __launch_bounds__(256) k_ztile_copy_out(const float *__restrict__ src, int H, int W, int HP, int WP, float *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_ztile_copy_out(const float *__restrict__ src, int rows, int W, int HP, int WP, float *__restrict__ dst, int y0)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x < W)
-        dst[((size_t)b * H + y) * W + x] = src[state_off(b, y + HALO, x + HALO, HP, WP)];
+        dst[((size_t)b * rows + y) * W + x] = src[state_off(b, y0 + y + HALO, x + HALO, HP, WP)];
 }
 
 // near-band pixel T of the image enumeration -> natural coordinates
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
             *dst = (ngx >= 0 && ngy >= 0) ? nm.x - ys : 0.f;  // samples above / left of the image count for the MSE trace only
             // the counted samples' share of the MSE trace, once per pixel: by the tile that owns its (clamped) position
             const int cy = min(max(ngy, 0), H - 1), cx = min(max(ngx, 0), W - 1);
-            if (cu > 0 && cy / VTY == ty && cx / VT == tx) {
+            if (cu > 0 && cy / VTY == ty && cx / VT == tx && cy >= za.tr_lo && cy < za.tr_hi) {
                 const float gu = nm.y - (float)cu * Yat(cy, cx);
                 sq += gu * gu / (float)cu;
             }
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
                 }
             });
         }
-        sq += (rowown && rowin && gy >= za.nby) ? sqf : 0.f;
+        sq += (rowown && rowin && gy >= za.nby && gy >= za.tr_lo && gy < za.tr_hi) ? sqf : 0.f;
         if (top && gy >= 0 && gy < za.nby) {
             const float *src = &Gt(gy + za.exy, 64 * u);  // zero outside the image (the near-band loop wrote every pixel)
 #pragma unroll
@@ -635,12 +638,26 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
            2 * align_up((size_t)B * ty * tx * 8);
 }
 
-static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
-                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
-                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
-                   double scale, double *errors, hipStream_t st)
-{
+// The state of a call between its launches: what iterate() keeps on its stack, and what a plan (srx_ibp_plan_*: the per-call tables built
+// once, iterations in several runs with the halo rows of a row band replaced in between) keeps alive.
+struct State {
     ZArgs za;
+    ZTabs tb;
+    float *s0, *s1;      // the two padded state planes; iteration `it` reads (it & 1 ? s1 : s0)
+    double *ep0, *ep1;   // per-tile MSE partials, alternating
+    const double *Vtot;
+    double scale;
+    int B, ntiles, it;
+    bool sep;
+    float *cur() const { return (it & 1) ? s1 : s0; }
+};
+
+static int setup(State &zs, const float *hr_init, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                 const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                 const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, double step, double scale, int tr_lo,
+                 int tr_hi, hipStream_t st)
+{
+    ZArgs &za = zs.za;
     za.H = H, za.W = W, za.tiles_x = cdiv(W, VT), za.tiles_y = cdiv(H, VTY);
     za.HP = za.tiles_y * VTY + 2 * HALO, za.WP = za.tiles_x * VT + 2 * HALO;
     const int HP = za.HP, WP = za.WP;
@@ -656,6 +673,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
     za.WT = W + za.exx, za.LN = za.exx + za.nbx, za.TOPN = (za.exy + za.nby) * za.WT;
     za.ngrp = NS / 4;
     za.sn = (float)step / (float)N;
+    za.tr_lo = tr_lo, za.tr_hi = tr_hi;
     const int NT = za.TOPN + (H - za.nby) * za.LN, ntiles = za.tiles_x * za.tiles_y;
     const size_t splane = (size_t)(HP + 2) * WP;
     float *Mt = ar.take<float>((size_t)B * HP * WP), *s0 = ar.take<float>(B * splane), *s1 = ar.take<float>(B * splane),
@@ -695,7 +713,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
     // padded state planes: zero borders (and trash rows) once, then the image
     if (hipMemsetAsync(s0, 0, B * splane * sizeof(float), st) != hipSuccess || hipMemsetAsync(s1, 0, B * splane * sizeof(float), st) != hipSuccess)
         return SRX_E_HIP;
-    hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0);
+    hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0, 0);
     SRX_CHECK_LAUNCH();
     if (NT > 0) {
         hipLaunchKernelGGL(k_ztile_near_tab, dim3(cdiv(NT, 256)), dim3(256), 0, st, ncu, nyx, NS, py.PB, px.PB, za, NT, nrec, nent);
@@ -703,28 +721,59 @@ static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::
         hipLaunchKernelGGL(k_ztile_near_m, dim3(cdiv(NT, 256), B), dim3(256), 0, st, Mg, Mu, NB, py.PB, px.PB, za, NT, Mn);
         SRX_CHECK_LAUNCH();
     }
-    ZTabs tb{Mt, Ct, CM, cmok, aw, k2, nrec, nent, Mn};
+    zs.tb = ZTabs{Mt, Ct, CM, cmok, aw, k2, nrec, nent, Mn};
+    zs.s0 = s0, zs.s1 = s1, zs.ep0 = ep0, zs.ep1 = ep1, zs.Vtot = Vtot, zs.scale = scale, zs.B = B, zs.ntiles = ntiles, zs.it = 0, zs.sep = sep;
+    return SRX_OK;
+}
+
+// n more iterations; errors: device [B][n] (or null), entry j = the trace of this run's iteration j
+static int run(State &zs, int n, double *errors, hipStream_t st)
+{
+    const ZArgs &za = zs.za;
     // ping-pong between the two padded planes (a tile reads its neighbours' pixels of the previous iteration)
-    const dim3 grid(za.tiles_x, za.tiles_y, B);
-    for (int it = 0; it < n_iter; it++) {
-        const float *src = (it & 1) ? s1 : s0;
-        float *dst = (it & 1) ? s0 : s1;
-        double *ep = errors ? ((it & 1) ? ep1 : ep0) : nullptr;
-        const double *eprev = errors && it > 0 ? ((it & 1) ? ep0 : ep1) : nullptr;  // the partial sums iteration it - 1 left
-        if (sep)
-            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<true>, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale,
-                       errors ? errors + it - 1 : nullptr, n_iter);
+    const dim3 grid(za.tiles_x, za.tiles_y, zs.B);
+    for (int j = 0; j < n; j++, zs.it++) {
+        const float *src = (zs.it & 1) ? zs.s1 : zs.s0;
+        float *dst = (zs.it & 1) ? zs.s0 : zs.s1;
+        double *ep = errors ? ((j & 1) ? zs.ep1 : zs.ep0) : nullptr;
+        const double *eprev = errors && j > 0 ? ((j & 1) ? zs.ep0 : zs.ep1) : nullptr;  // the partial sums iteration j - 1 left
+        if (zs.sep)
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<true>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
+                       errors ? errors + j - 1 : nullptr, n);
         else
-            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<false>, grid, dim3(256 * NSY), 0, st, src, dst, tb, za, ep, eprev, Vtot, scale,
-                       errors ? errors + it - 1 : nullptr, n_iter);
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<false>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
+                       errors ? errors + j - 1 : nullptr, n);
     }
-    if (errors) {
-        hipLaunchKernelGGL(k_ztile_trace, dim3(B), dim3(256), 0, st, ((n_iter - 1) & 1) ? ep1 : ep0, ntiles, Vtot, scale, errors + n_iter - 1, n_iter);
+    if (errors && n > 0) {
+        hipLaunchKernelGGL(k_ztile_trace, dim3(zs.B), dim3(256), 0, st, ((n - 1) & 1) ? zs.ep1 : zs.ep0, zs.ntiles, zs.Vtot, zs.scale, errors + n - 1, n);
         SRX_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_ztile_copy_out, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, (n_iter & 1) ? s1 : s0, H, W, HP, WP, hr);
+    return SRX_OK;
+}
+
+// image rows [y0, y0 + rows) of the current state -> / <- a packed [B][rows][W] buffer
+static int rows_out(const State &zs, int y0, int rows, float *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ztile_copy_out, dim3(cdiv(zs.za.W, 256), rows, zs.B), dim3(256), 0, st, zs.cur(), rows, zs.za.W, zs.za.HP, zs.za.WP, dst, y0);
     SRX_CHECK_LAUNCH();
     return SRX_OK;
+}
+static int rows_in(const State &zs, int y0, int rows, const float *src, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(zs.za.W, 256), rows, zs.B), dim3(256), 0, st, src, rows, zs.za.W, zs.za.HP, zs.za.WP, zs.cur(), y0);
+    SRX_CHECK_LAUNCH();
+    return SRX_OK;
+}
+
+static int iterate(const float *hr_init, float *hr, int B, int N, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px,
+                   const fused::Kernel7<float> &kc, const fused::Kernel7<float> &kt, const float *Mg, const float *Cg, const float *Mu,
+                   const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
+                   double scale, double *errors, hipStream_t st)
+{
+    State zs;
+    SRX_TRY(setup(zs, hr_init, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, step, scale, 0, H, st));
+    SRX_TRY(run(zs, n_iter, errors, st));
+    return rows_out(zs, 0, H, hr, st);
 }
 
 }  // namespace ztile

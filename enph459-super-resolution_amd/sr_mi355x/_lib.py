@@ -35,6 +35,9 @@ _TYPED = {
     "srx_mean_frames_{T}": (_I, [_P, _I, _I, _Z, _P, _P]),
     "srx_u8_to_{T}": (_I, [_P, _Z, _P, _P]),
     "srx_quantize_u8_{T}": (_I, [_P, _Z, _P, _P]),
+    "srx_ibp_plan_create_{T}": (_I, [_P, _I, _I, _I, _I, _HD, _HD, _I, _I, _P, _I, _I, _I, _D, _I, _I, _P, _Z, _P, _U, _c.POINTER(_P)]),
+    "srx_ibp_plan_get_rows_{T}": (_I, [_P, _I, _I, _P, _P]),
+    "srx_ibp_plan_set_rows_{T}": (_I, [_P, _I, _I, _P, _P]),
     "srx_pair_moments_{T}": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "srx_local_contrast_{T}": (_I, [_P, _I, _I, _I, _P, _P]),
     "srx_ring_sums_{T}": (_I, [_P, _I, _I, _D, _D, _I, _P, _P, _Z, _P]),
@@ -57,6 +60,11 @@ _PLAIN = {
     "srx_saa_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "srx_ibp_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _U]),
     "srx_ibp_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _HD, _HD, _I, _I, _U]),
+    "srx_ibp_plan_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _U]),
+    "srx_ibp_plan_run": (_I, [_P, _I, _P, _P]),
+    "srx_ibp_plan_path": (_c.c_char_p, [_P]),
+    "srx_ibp_plan_supports_trace_rows": (_I, [_P]),
+    "srx_ibp_plan_destroy": (None, [_P]),
     "srx_metrics_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "srx_edge_magnitude_f64": (_I, [_P, _I, _I, _D, _P, _P, _Z, _P]),
     "srx_edge_dist_range": (_I, [_I, _I, _D, _D, _D, _I, _P, _P]),

@@ -235,6 +235,63 @@ def ibp_batched(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, p
     return hr, errors
 
 
+class IbpPlan:
+    """srx_ibp_plan_* (include/srx.h): the IBP loop of a batch in instalments -- the per-call tables built once, `run(n)` for n more
+    iterations, rows of the state readable / replaceable in between.  `trace_rows=(lo, hi)`: the HR rows whose LR samples the MSE trace
+    counts (a row band of a larger image counts its own rows only; `supports_trace_rows` says whether this plan can).  The tensors
+    passed in and the workspace live as long as the plan."""
+
+    def __init__(self, lr, shifts_yx, kernel, hr_init, factor=2, step=0.5, precision=None, flags=FLAG_AUTO, trace_rows=None):
+        self.prec = precision or get_precision()
+        self.lr, _ = _to_dev(lr, self.prec)
+        h0, _ = _to_dev(hr_init, self.prec)
+        self.B, self.N, self.h, self.w = self.lr.shape
+        _, self.H, self.W = h0.shape
+        self._sh = _host_f64(shifts_yx, (self.N, 2))
+        self._k = _host_f64(kernel)
+        lo, hi = trace_rows if trace_rows is not None else (0, self.H)
+        lib = _lib.load()
+        self._ws = _ws(lib.srx_ibp_plan_workspace_bytes(_ELEM[self.prec], self.B, self.N, self.h, self.w, self.H, self.W, int(factor), flags))
+        self._h = ctypes.c_void_p()
+        k = self._k[0]
+        _lib.check(_fn("srx_ibp_plan_create", self.prec)(_p(self.lr), self.B, self.N, self.h, self.w, self._sh[1], self._k[1], k.shape[0], k.shape[1],
+                                                         _p(h0), self.H, self.W, int(factor), float(step), int(lo), int(hi), self._ws[1], self._ws[2],
+                                                         _stream(), flags, ctypes.byref(self._h)), "srx_ibp_plan_create")
+        self.path = lib.srx_ibp_plan_path(self._h).decode()
+        self.supports_trace_rows = bool(lib.srx_ibp_plan_supports_trace_rows(self._h))
+
+    def run(self, n_iter, want_errors=True):
+        """n more iterations -> errors float64 [B, n] on the device (this run's slice of the trace) or None"""
+        errors = torch.empty((self.B, int(n_iter)), dtype=torch.float64, device=self.lr.device) if want_errors and n_iter > 0 else None
+        _lib.check(_lib.load().srx_ibp_plan_run(self._h, int(n_iter), _p(errors) if errors is not None else None, _stream()), "srx_ibp_plan_run")
+        return errors
+
+    def get_rows(self, lo, hi, out=None):
+        out = torch.empty((self.B, hi - lo, self.W), dtype=_TORCH_DT[self.prec], device=self.lr.device) if out is None else out
+        _lib.check(_fn("srx_ibp_plan_get_rows", self.prec)(self._h, int(lo), int(hi), _p(out), _stream()), "srx_ibp_plan_get_rows")
+        return out
+
+    def set_rows(self, lo, hi, rows):
+        rows = rows.to(device=self.lr.device, dtype=_TORCH_DT[self.prec]).contiguous()
+        if tuple(rows.shape) != (self.B, hi - lo, self.W):
+            raise ValueError(f"rows must have shape {(self.B, hi - lo, self.W)}")
+        _lib.check(_fn("srx_ibp_plan_set_rows", self.prec)(self._h, int(lo), int(hi), _p(rows), _stream()), "srx_ibp_plan_set_rows")
+
+    def result(self):
+        return self.get_rows(0, self.H)
+
+    def close(self):
+        if self._h:
+            _lib.load().srx_ibp_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------------------
 # the reference's call surface (single image; numpy or torch)
 # ------------------------------------------------------------------------------------------

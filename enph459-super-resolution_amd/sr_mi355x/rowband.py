@@ -14,6 +14,17 @@ of the [n_iter] vector at the end of the call completes it -- the trace never fe
 
 The compute behind the cut is an "engine" (duck-typed): `GpuEngine` below drives libsrx; the CPU test plugs in the oracle.  Nothing
 here imports the oracle.
+
+Round 4.  The GPU engine runs a PLAN (srx_ibp_plan_*, api.IbpPlan): the per-call tables of the sub-image are built once, a round is
+`plan.run(m)` -- m iteration launches and nothing else -- and the halo rows are read from / written into the plan's state in place.
+Where the plan can restrict the MSE trace to a row range (the float32 integer-shift frame kernel: the reference's mono_cal_target
+geometry), the trace comes out of the iteration kernels themselves -- each rank counts the LR samples that land on its own HR rows, so
+the ranks' sums add up to the whole image's -- and `want_errors` costs nothing; elsewhere the trace still takes one forward model per
+frame and iteration (`sse_rows`) and single-iteration runs.  Round 3 rebuilt the tables on every round and always paid the forward
+models: >= 15x the single-GPU cost per iteration before any halo traffic (the round-3 review's weak point 9).
+The sends of a round are issued on a side stream as soon as the round is queued and the receives are waited for right before the next
+round's launches; with ONE launch stream per rank that hides the host-side latency of the point-to-point calls, not the transfer itself
+(iterating the interior tiles while the halo is in flight would: not built).  `stats` reports the split.
 """
 import math
 
@@ -80,9 +91,13 @@ class GpuEngine:
         return tot
 
     def halo_stream(self):
-        """A side stream for the halo traffic: the rows a neighbour needs leave while this rank is still iterating (ibp_row_bands
-        sends them as soon as the round that produced them is queued, and waits for the neighbours' rows only before the next round)."""
+        """A side stream for the halo traffic (ibp_row_bands issues the sends on it as soon as the round that produced the rows is
+        queued, and waits for the neighbours' rows only before the next round)."""
         return self.torch.cuda.Stream()
+
+    def plan(self, lr_sub, hr_sub, trace_rows):
+        """The sub-image's IBP loop as a plan (api.IbpPlan): tables once, run(n), rows in place."""
+        return self.api.IbpPlan(lr_sub[None], self.shifts, self.kernel, hr_sub[None], self.f, self.step, precision=self.prec, trace_rows=trace_rows)
 
     def rows_to_wire(self, t, on_device):  # a block of rows as a contiguous tensor the process group can send
         t = t.contiguous()
@@ -113,8 +128,95 @@ def _group_info(group):
     return None, 0, 1, None
 
 
+def _ibp_row_bands_plan(eng, dist, group, backend, rank, world, lr_sub, hr_sub, a, b, A, B, f, N, h, w, W, n_iter, m, halo_rows, want_errors, stats):
+    """The GPU engine's loop: one plan per call, a round = plan.run(n); halo rows leave and arrive through plan.get_rows / set_rows."""
+    import time
+    torch = eng.torch
+    own = (a - A, b - A)
+    plan = eng.plan(lr_sub, hr_sub, own)
+    in_kernel_trace = want_errors and plan.supports_trace_rows
+    on_dev = backend is not None and "nccl" in backend
+    up, dn = (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
+    side = eng.halo_stream() if on_dev else None
+    h_sub = (B - A) // f
+    parts = []      # in-kernel trace: per round a device vector [n] (the library's mean over the SUB-image's samples; rescaled below)
+    sse_parts = []  # otherwise: one device scalar per iteration (sse_rows: a forward model per frame)
+    t_compute = t_exchange = 0.0
+    pending = None  # (requests, [(halo_lo, recv buffer)]) of the exchange in flight
+    ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if stats is not None else (None, None)
+
+    def start_exchange():
+        ops, recvs = [], []
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side) if side is not None else _null()
+        with ctx:
+            for nb, own_lo, halo_lo in ((up, a - A, a - A - halo_rows), (dn, b - A - halo_rows, b - A)):
+                if nb is None:
+                    continue
+                send = plan.get_rows(own_lo, own_lo + halo_rows)[0]
+                send = send if on_dev else send.cpu()
+                recv = eng.empty_wire(halo_rows, W, on_dev)
+                ops += [dist.P2POp(dist.isend, send, nb, group), dist.P2POp(dist.irecv, recv, nb, group)]
+                recvs.append((halo_lo, recv))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+        return reqs, recvs
+
+    def finish_exchange(reqs, recvs):
+        for r in reqs:
+            r.wait()
+        ctx = torch.cuda.stream(side) if side is not None else _null()
+        with ctx:
+            for halo_lo, recv in recvs:
+                plan.set_rows(halo_lo, halo_lo + halo_rows, recv.to("cuda")[None])
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)  # the next round reads the halo rows
+
+    it = 0
+    while it < n_iter:
+        n = min(m, n_iter - it)
+        if pending is not None:
+            t0 = time.perf_counter()
+            finish_exchange(*pending)
+            t_exchange += time.perf_counter() - t0
+            pending = None
+        if stats is not None:
+            ev0.record()
+        if in_kernel_trace:
+            parts.append(plan.run(n, want_errors=True)[0])
+        elif want_errors:
+            for _ in range(n):
+                cur = plan.get_rows(0, B - A)[0]
+                sse_parts.append(eng.sse_rows(lr_sub, cur, own[0] // f, own[1] // f))
+                plan.run(1, want_errors=False)
+        else:
+            plan.run(n, want_errors=False)
+        if stats is not None:
+            ev1.record()
+            ev1.synchronize()
+            t_compute += ev0.elapsed_time(ev1) * 1e-3
+        it += n
+        if world > 1 and it < n_iter:
+            t0 = time.perf_counter()
+            pending = start_exchange()
+            t_exchange += time.perf_counter() - t0
+    band = plan.get_rows(own[0], own[1])[0]
+    sse = None
+    if want_errors:
+        if in_kernel_trace:  # mean over N h_sub w samples of the sub-image -> the sum over this rank's own samples
+            sse = (torch.cat(parts) * float(N * h_sub * w)).cpu().numpy() if parts else np.zeros(0)
+        else:
+            sse = torch.stack(sse_parts).cpu().numpy() if sse_parts else np.zeros(0)
+    out = eng.to_host(band)
+    if stats is not None:
+        stats.update(rounds=-(-n_iter // m), compute_s=t_compute, exchange_host_s=t_exchange, plan_path=plan.path, trace="in the iteration kernels" if in_kernel_trace
+                     else ("forward model per frame and iteration" if want_errors else "none"))
+    plan.close()
+    return out, sse
+
+
 def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5, *, engine=None, precision="f32", halo_rows=None,
-                  iters_per_exchange=1, want_errors=True, group=None):
+                  iters_per_exchange=1, want_errors=True, group=None, stats=None):
     """IBP of ONE image on all ranks of the process group.  Every rank passes the same full arrays lr [N, h, w] and hr_init [H, W]
     (host); each iterates on its own row band.  Returns (band, errors, (a, b)): the rank's owned rows [a, b) of the result as a
     float64 numpy array, and the complete MSE trace (list of n_iter floats, identical on every rank; None if not wanted).
@@ -138,7 +240,11 @@ def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5,
     hr_sub = eng.load(hr_init[A:B])
     on_dev = backend is not None and "nccl" in backend  # CUDA tensors travel over RCCL; a gloo-only group gets host copies
     up, dn = (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
-    sse_parts = []  # one scalar per iteration: device scalars for the GPU engine (read once, at the end), floats for a host engine
+    if hasattr(eng, "plan"):  # the GPU engine: one plan per call (tables once, in-kernel trace where the plan has it)
+        band, sse = _ibp_row_bands_plan(eng, dist, group, backend, rank, world, lr_sub, hr_sub, a, b, A, B, f, N, h, w, W, n_iter, m, halo_rows,
+                                        want_errors, stats)
+        return band, _finish_trace(sse, dist, group, backend, world, N, h, w) if want_errors else None, (a, b)
+    sse_parts = []  # one scalar per iteration: device scalars for a GPU engine (read once, at the end), floats for a host engine
     side = eng.halo_stream() if (on_dev and hasattr(eng, "halo_stream")) else None
 
     def exchange():
@@ -177,19 +283,25 @@ def ibp_row_bands(lr, shifts_yx, kernel, hr_init, factor=2, n_iter=80, step=0.5,
             exchange()
     errors = None
     if want_errors:
-        if sse_parts and hasattr(sse_parts[0], "device"):  # device scalars: ONE transfer for the whole trace
-            import torch
+        import torch
+        if sse_parts and isinstance(sse_parts[0], torch.Tensor):  # device scalars: ONE transfer for the whole trace
             sse = torch.stack(sse_parts).cpu().numpy()
-        else:
+        else:  # (numpy >= 2 scalars also have a `.device`: the type is what tells a host engine's floats apart)
             sse = np.asarray(sse_parts, dtype=np.float64)
-        if world > 1:
-            import torch
-            t = torch.from_numpy(sse)
-            t = t if "gloo" in backend else t.cuda()  # a host vector wherever the group has a host backend
-            dist.all_reduce(t, group=group)  # the one collective of the call: completes the trace
-            sse = t.cpu().numpy()
-        errors = [float(v) / (N * h * w) for v in sse]
+        errors = _finish_trace(sse, dist, group, backend, world, N, h, w)
     return eng.to_host(hr_sub[a - A:b - A]), errors, (a, b)
+
+
+def _finish_trace(sse, dist, group, backend, world, N, h, w):
+    """this rank's sums of squared residuals per iteration -> the whole image's MSE trace (ONE all-reduce: the call's only collective)"""
+    sse = np.ascontiguousarray(np.asarray(sse, dtype=np.float64))
+    if world > 1:
+        import torch
+        t = torch.from_numpy(sse.copy())
+        t = t if "gloo" in backend else t.cuda()  # a host vector wherever the group has a host backend
+        dist.all_reduce(t, group=group)
+        sse = t.cpu().numpy()
+    return [float(v) / (N * h * w) for v in sse]
 
 
 def gather_rows(band, bounds, H, dst=0, group=None):

@@ -163,8 +163,15 @@ def reconstruct(frames, shifts, psf_kernel, n_iter, factor=UPSAMPLE_FACTOR, step
     saa = api.shift_and_add_batched(lr[None], shifts, factor)
     if row_bands:
         from . import rowband
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        m = 2  # two iterations per halo exchange (half the messages) where the bands are tall enough for the doubled halo
+        try:
+            rowband.band_plan(lr.shape[1], factor, world, m * rowband.reach_rows(factor, shifts, np.asarray(psf_kernel).shape[0], api.get_precision()))
+        except ValueError:
+            m = 1
         band, errs, bounds = rowband.ibp_row_bands(lr, shifts, psf_kernel, saa[0], factor, n_iter, step, precision=api.get_precision(),
-                                                   iters_per_exchange=2)
+                                                   iters_per_exchange=m)
         full = rowband.gather_rows(band, bounds, saa.shape[1])
         hr0 = None if full is None else torch.from_numpy(full).to(saa)
         return {"native_2x": native, "SAA": saa[0], "SAA_IBP": hr0, "LR_mean": mean_lr}, errs

@@ -154,6 +154,34 @@ int srx_ibp_f64(const double *lr, int B, int N, int h, int w, const double *shif
                 int kw, const double *hr_init, int H, int W, int factor, int n_iter, double step, double *hr_out,
                 double *errors_out, void *ws, size_t ws_bytes, srx_stream_t stream, unsigned flags);
 
+/* ---- the same loop as a PLAN: tables built once, the iterations in several runs, rows of the state readable / replaceable in between ----
+ * No reference counterpart (its ibp() is one call); this is what running ONE image on several GPUs needs (second row: row bands
+ * with a halo exchange every few iterations, sr_mi355x/rowband.py), and what any caller that iterates in instalments saves: the ~0.5 ms of
+ * per-call table building around a 39 us iteration.
+ *   create : as srx_ibp_* without n_iter; [trace_row_lo, trace_row_hi) = the HR rows whose LR samples the MSE trace counts (a sample belongs to the
+ *            HR row it lands on, clamped to the image): 0, H for a whole image, a rank's own rows for a row band -- the ranks' traces then add up
+ *            to the whole image's.  lr, workspace (srx_ibp_plan_workspace_bytes) and the plan stay alive until destroy.
+ *   run    : n more iterations; errors (device float64 [B, n], may be NULL) = this run's slice of the trace.  SRX_E_UNSUPPORTED if a trace over a
+ *            row range is asked of a plan that cannot restrict it (srx_ibp_plan_supports_trace_rows() == 0: every path but the float32
+ *            integer-shift frame kernel, whose tables the plan hoists; the others run a whole srx_ibp call per run)
+ *   get / set_rows : HR rows [row_lo, row_hi) of the current state <-> a packed [B, rows, W] device buffer */
+typedef struct srx_plan_s srx_plan_t;
+size_t srx_ibp_plan_workspace_bytes(int elem_bytes, int B, int N, int h, int w, int H, int W, int factor, unsigned flags);
+int srx_ibp_plan_create_f32(const float *lr, int B, int N, int h, int w, const double *shifts_yx, const double *kernel, int kh, int kw,
+                            const float *hr_init, int H, int W, int factor, double step, int trace_row_lo, int trace_row_hi, void *ws,
+                            size_t ws_bytes, srx_stream_t stream, unsigned flags, srx_plan_t **plan);
+int srx_ibp_plan_create_f64(const double *lr, int B, int N, int h, int w, const double *shifts_yx, const double *kernel, int kh, int kw,
+                            const double *hr_init, int H, int W, int factor, double step, int trace_row_lo, int trace_row_hi, void *ws,
+                            size_t ws_bytes, srx_stream_t stream, unsigned flags, srx_plan_t **plan);
+int srx_ibp_plan_run(srx_plan_t *plan, int n_iter, double *errors_out, srx_stream_t stream);
+int srx_ibp_plan_get_rows_f32(srx_plan_t *plan, int row_lo, int row_hi, float *dst, srx_stream_t stream);
+int srx_ibp_plan_set_rows_f32(srx_plan_t *plan, int row_lo, int row_hi, const float *src, srx_stream_t stream);
+int srx_ibp_plan_get_rows_f64(srx_plan_t *plan, int row_lo, int row_hi, double *dst, srx_stream_t stream);
+int srx_ibp_plan_set_rows_f64(srx_plan_t *plan, int row_lo, int row_hi, const double *src, srx_stream_t stream);
+const char *srx_ibp_plan_path(srx_plan_t *plan);          /* "ztile" (tables hoisted) or "call per run" */
+int srx_ibp_plan_supports_trace_rows(srx_plan_t *plan);
+void srx_ibp_plan_destroy(srx_plan_t *plan);
+
 /* ---- index maps and pointwise glue of the drivers (bit-exact) ----
  * decimate:    out[i, j] = in[py + i*f, px + j*f]     `shifted[::f, ::f]` run_sr.py:165;
  *              with f=2, py=px=0 it is extract_red (rgb_cal_target/run_sr.py:73-75).

@@ -19,11 +19,14 @@ def main():
     from sr_mi355x import rowband
     d = np.load(sys.argv[1])
     f, n_iter, m = int(d["f"]), int(d["n_iter"]), int(d["m"])
+    stats = {}
     band, errs, bounds = rowband.ibp_row_bands(d["lr"], d["shifts"], d["psf"], d["hr0"], f, n_iter, 0.5, precision=str(d["prec"]),
-                                               iters_per_exchange=m)
+                                               iters_per_exchange=m, stats=stats)
     full = rowband.gather_rows(band, bounds, d["hr0"].shape[0])
     if dist.get_rank() == 0:
-        np.savez(sys.argv[2], hr=full, errors=np.asarray(errs), world=dist.get_world_size())
+        print(f"row bands, rank 0 of {dist.get_world_size()}: {stats}")  # the per-round split: compute (HIP events) / exchange (host time in the P2P calls)
+        np.savez(sys.argv[2], hr=full, errors=np.asarray(errs), world=dist.get_world_size(), plan_path=stats.get("plan_path", ""), trace=stats.get("trace", ""),
+                 rounds=stats.get("rounds", 0), compute_s=stats.get("compute_s", 0.0), exchange_host_s=stats.get("exchange_host_s", 0.0))
     dist.barrier()
     dist.destroy_process_group()
 

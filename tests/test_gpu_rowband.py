@@ -22,6 +22,7 @@ def _launch(tmp_path, world, port, **case):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = np.load(tmp_path / "out.npz")
     assert int(out["world"]) == world
+    _launch.last = {k: out[k].item() for k in ("plan_path", "trace", "rounds", "compute_s", "exchange_host_s")}
     return out["hr"], out["errors"]
 
 
@@ -52,3 +53,93 @@ def test_row_bands_equal_single_gpu_and_oracle(tmp_path, name, world, prec, m):
     assert hr.shape == ref.shape
     assert np.abs(hr - ref).max() < tol and np.abs(hr - one).max() < tol
     assert np.allclose(errs, ref_errs, rtol=rtol, atol=0) and np.allclose(errs, one_errs, rtol=rtol, atol=0)
+    st = _launch.last
+    # the reference's geometry in float32 runs on hoisted tables with the trace out of the iteration kernels; the rest a library call per run
+    if name == "nominal_f2" and prec == "f32":
+        assert st["plan_path"] == "ztile" and st["trace"] == "in the iteration kernels"
+    else:
+        assert st["plan_path"] == "call per run" and st["trace"].startswith("forward model")
+    assert st["rounds"] == -(-n_iter // m) and st["compute_s"] > 0.0
+    print(f"{name} world={world} {prec} m={m}: {st}")
+
+
+def test_plan_in_instalments_equals_one_call():
+    """srx_ibp_plan_*: tables once, iterations in instalments, rows read and written in place.  run(3) + run(2) + run(1) = one 6-iteration call
+    (state and trace, bit for bit) for the hoisted float32 frame kernel and for the call-per-run form (float64; a x4 phase grid); a trace
+    over a row range adds up over a partition of the rows; get_rows / set_rows round-trip."""
+    import torch
+    import sr_mi355x as S
+    from sr_mi355x import api
+    psf = synth.gaussian_psf()
+    for f, shifts, (h, w), prec, path in ((2, synth.NOMINAL_5, (150, 277), "f32", "ztile"), (2, synth.NOMINAL_5, (90, 140), "f64", "call per run"),
+                                          (4, synth.phase_shifts(4), (40, 50), "f32", "call per run")):
+        S.set_precision(prec)
+        try:
+            lr = torch.round(torch.rand((2, len(shifts), h, w), device="cuda", dtype=torch.float64) * 255)
+            saa = S.shift_and_add_batched(lr, shifts, f)
+            one, e1 = S.ibp_batched(lr, shifts, psf, saa, f, 6, 0.5)
+            p = api.IbpPlan(lr, shifts, psf, saa, f, 0.5)
+            assert p.path == path
+            parts = [p.run(3), p.run(2), p.run(1)]
+            assert torch.equal(p.result(), one) and torch.equal(torch.cat(parts, dim=1), e1)
+            rows = p.get_rows(10, 30)
+            assert torch.equal(rows, one[:, 10:30])
+            p.set_rows(10, 30, torch.zeros_like(rows))
+            assert float(p.get_rows(10, 30).abs().max()) == 0.0 and torch.equal(p.get_rows(0, 10), one[:, :10])
+            p.close()
+            if path == "ztile":  # the trace over [0, c) plus the trace over [c, H) is the whole image's
+                H = h * f
+                for cut in (2, 52, 131, H - 1):
+                    ea = api.IbpPlan(lr, shifts, psf, saa, f, 0.5, trace_rows=(0, cut)).run(4)
+                    eb = api.IbpPlan(lr, shifts, psf, saa, f, 0.5, trace_rows=(cut, H)).run(4)
+                    np.testing.assert_allclose((ea + eb).cpu().numpy(), e1[:, :4].cpu().numpy(), rtol=1e-8)  # (a lane adds its row's squares in float32 before the float64 sums)
+                    assert float(ea.min()) >= 0.0 and float(eb.min()) >= 0.0
+            else:
+                q = api.IbpPlan(lr, shifts, psf, saa, f, 0.5, trace_rows=(0, 10))
+                assert not q.supports_trace_rows
+                with pytest.raises(Exception):
+                    q.run(1)
+                q.run(1, want_errors=False)
+        finally:
+            S.set_precision("f32")
+
+
+def test_one_rank_row_band_call_costs_what_the_plain_call_costs():
+    """world = 1 through rowband.ibp_row_bands with the MSE trace (what `run_sr --row-bands` does per rank): the same image and trace as
+    the plain call, and -- on the reference's mono_cal_target size, 1536 x 2048 -> 3072 x 4096, N = 5, 80 iterations, device tensors in and a
+    host image out on both sides -- within 1.15x of its time (round 3: one library call and N forward models per iteration, >= 15x)."""
+    import time
+    import torch
+    import sr_mi355x as S
+    from sr_mi355x import rowband
+    S.set_precision("f32")
+    f, shifts, psf, (h, w), n_iter = 2, synth.NOMINAL_5, synth.gaussian_psf(), (1536, 2048), 80
+    lr = torch.round(torch.rand((len(shifts), h, w), device="cuda") * 255)
+    saa = S.shift_and_add_batched(lr[None], shifts, f)[0]
+    lr_h, saa_h = lr, saa  # (device tensors: the engine uploads nothing)
+
+    def plain():
+        hr, e = S.ibp_batched(lr[None], shifts, psf, saa[None], f, n_iter, 0.5)
+        return hr[0].double().cpu().numpy(), e[0].cpu().numpy()
+
+    def banded(stats=None):
+        band, errs, _ = rowband.ibp_row_bands(lr_h, shifts, psf, saa_h, f, n_iter, 0.5, precision="f32", iters_per_exchange=2, stats=stats)
+        return band, np.asarray(errs)
+    a, ea = plain()
+    st = {}
+    b, eb = banded(st)
+    assert st["plan_path"] == "ztile" and st["trace"] == "in the iteration kernels"
+    assert np.array_equal(a, b)
+    np.testing.assert_allclose(ea, eb, rtol=1e-12)
+    ts = {}
+    for name, fn in (("plain", plain), ("banded", banded)):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        ts[name] = best
+    print(f"one rank, {n_iter} iterations on {h * f} x {w * f}: plain {ts['plain'] * 1e3:.2f} ms, row-band path {ts['banded'] * 1e3:.2f} ms (host copies included in both)")
+    assert ts["banded"] < 1.15 * ts["plain"]
