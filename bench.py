@@ -73,6 +73,8 @@ def kernel_model_bytes(name, B, N, h, w, f, eb, n_iter):
         "k_ibp_ctile": 2 * hw + lrn,
         "k_ibp_afwd": 2 * hw + lrn,             # read hr + the LR mosaic, write G
         "k_ibp_abwd": 3 * hw,                   # read G + hr, write hr
+        "k_ibp_sv": 3 * hw,                     # read G' + hr, write hr (and Yv: the next launch's input, counted there)
+        "k_ibp_sh": hw + lrn + hw,              # read Yv + the LR mosaic, write G'
         "k_ibp_bfwd": hw + 2 * lrn,             # read hr + the LR frames, write the residuals
         "k_ibp_bbwd": lrn + 2 * hw,             # read the residuals + hr, write hr
     }.get(name)
@@ -200,6 +202,9 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
     per_iter = {k: v["avg_us"] for k, v in kernels.items() if v["launches"] == n_iter and k != "k_ibp_patch"}
     if "k_ibp_dtile" in kernels:  # a pair of launches per iteration (byte / float form of the mosaic: an item is iterated by exactly one)
         per_iter["k_ibp_dtile"] = kernels["k_ibp_dtile"]["total_ms"] * 1e3 / n_iter
+    for kn in ("k_ibp_sv", "k_ibp_sh"):  # float64 strips: n_iter + 1 vertical launches (the first and the last do half the work), a pair of
+        if kn in kernels:                 # horizontal launches per iteration (byte / float form of the mosaic)
+            per_iter[kn] = kernels[kn]["total_ms"] * 1e3 / n_iter
     if "k_ibp_patch" in kernels:  # all iterations of a patch in one launch
         per_iter["k_ibp_patch"] = kernels["k_ibp_patch"]["total_ms"] * 1e3 / n_iter
     out["kernels"] = kernels
@@ -213,7 +218,7 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
                             "frac": round(it_bytes / (t_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         # k_ibp_patch runs as a pair of launches (byte / float form of the mosaic; a patch is iterated by exactly one of them, the
         # other's blocks leave at once): "one launch" of the roofline is the pair
-        launch_us = (round(kernels[dom]["total_ms"] * 1e3, 2) if dom == "k_ibp_patch" else round(per_iter[dom], 2) if dom == "k_ibp_dtile"
+        launch_us = (round(kernels[dom]["total_ms"] * 1e3, 2) if dom == "k_ibp_patch" else round(per_iter[dom], 2) if dom in ("k_ibp_dtile", "k_ibp_sv", "k_ibp_sh")
                      else kernels[dom]["avg_us"])
         out["dominant"] = {"kernel": dom, "avg_launch_us": launch_us, "algorithmic_bytes_per_launch": nbytes,
                            "achieved": round(nbytes / (launch_us * 1e-6) / 1e9, 1) if nbytes else None,

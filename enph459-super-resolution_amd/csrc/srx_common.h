@@ -95,6 +95,8 @@ enum KernelId {
     KID_PATCH_BUILD,
     KID_PATCH_FLAGS,
     KID_ATILE_NEAR,
+    KID_IBP_SV,
+    KID_IBP_SH,
     KID_COUNT
 };
 

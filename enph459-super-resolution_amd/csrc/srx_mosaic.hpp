@@ -67,6 +67,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
                    const int *ncu, const int *nyx, int NS, int NB, const double *Vtot, Arena &ar, int H, int W, int n_iter, double step,
                    double scale, double *errors, hipStream_t st);
 }  // namespace atile
+namespace stile {  // srx_stile.hpp: float64 patches with a common fraction > 0 as two launches per iteration on register-resident strips
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline size_t tabs_bytes(int eb, int B, int N);
+template <typename T>
+static int iterate(const T *hr_init, T *hr, int B, int N, int f, const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, const fused::Kernel7<T> &kc,
+                   const fused::Kernel7<T> &kt, const T *Mg, const T *Cg, const T *Mu, const int *ncu, const int *nyx, int NS, int NB, const double *Vtot,
+                   Arena &ar, int n_iter, double step, double scale, double *errors, hipStream_t st);
+}
 namespace mosaic {
 struct MTap;
 }
@@ -1088,12 +1096,14 @@ __global__ void __launch_bounds__(256)
 // one of them uses (M, C, Mu, the tap tables, the near-band lists):
 //   tiles : the blurred plane, G, per-tile MSE partials      patch : srx_patch.hpp's operand planes and tables
 //   ztile : srx_ztile.hpp's padded state / operand planes and tables
-enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3, IMPL_CTILE = 4, IMPL_ATILE = 5 };
+enum Impl { IMPL_TILES = 0, IMPL_PATCH = 1, IMPL_ZTILE = 2, IMPL_DTILE = 3, IMPL_CTILE = 4, IMPL_ATILE = 5, IMPL_STILE = 6 };
 
 static inline Impl choose_impl(int eb, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
     if (eb == 4 && !(call_flags() & (SRX_FLAG_TILES | SRX_FLAG_DIAG_WIDE_WINDOWS)) && patch::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_PATCH;
+    if (stile::eligible(eb, N, H, W, sh, k, kh, kw, f))
+        return IMPL_STILE;
     if (ctile::eligible(eb, N, H, W, sh, k, kh, kw, f))
         return IMPL_CTILE;
     if (ztile::eligible(eb, N, H, W, sh, k, kh, kw, f))
@@ -1130,6 +1140,8 @@ static inline size_t ws_impl(Impl im, int eb, int B, int N, int H, int W)
         return ctile::tabs_bytes(eb, B, N, H, W);
     if (im == IMPL_ATILE)
         return atile::tabs_bytes(B, N, H, W);
+    if (im == IMPL_STILE)
+        return stile::tabs_bytes(eb, B, N);
     return align_up((size_t)B * Hp * Wp * eb) + align_up((size_t)B * Hg * Wg * eb) +
            align_up((size_t)B * cdiv((int)Hg, 32) * cdiv((int)Wg, 32) * sizeof(double));
 }
@@ -1140,6 +1152,8 @@ static inline size_t ibp_ws(int eb, int B, int N, int H, int W)
     size_t m = ws_impl(IMPL_TILES, eb, B, N, H, W);
     if (eb == 4 && H == 256 && W == 256)
         m = std::max(m, ws_impl(IMPL_PATCH, eb, B, N, H, W));
+    if (eb == 8 && H == 256 && W == 256)
+        m = std::max(m, ws_impl(IMPL_STILE, eb, B, N, H, W));
     if (eb == 4 && H >= 128 && W >= 128)
         m = std::max(m, ws_impl(IMPL_ZTILE, eb, B, N, H, W));
     // every shape dtile::plan() admits: 256-row windows of 192 (4 x 3 waves) or 256 columns, origins on row quads / 16-column groups
@@ -1244,7 +1258,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
 {
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD, Hg = Hp + 3, Wg = Wp + 3;
     const Impl impl = choose_impl((int)sizeof(T), N, H, W, sh, k, kh, kw, f);
-    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : impl == IMPL_ATILE ? "atile" : "mosaic";  // what srx_last_path() reports: the branch taken
+    *took = impl == IMPL_PATCH ? "patch" : impl == IMPL_ZTILE ? "ztile" : impl == IMPL_DTILE ? "dtile" : impl == IMPL_CTILE ? "ctile" : impl == IMPL_ATILE ? "atile" : impl == IMPL_STILE ? "stile" : "mosaic";  // what srx_last_path() reports: the branch taken
     const size_t P = (size_t)B * H * W;
     if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SRX_E_HIP;
@@ -1277,6 +1291,10 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     }
     const double scale = 1.0 / ((double)h * (double)w) / (double)N;
     // integer HR shifts on a large frame, rows along the registers and columns along the lanes (float64; float32 on request)
+    if constexpr (sizeof(T) == 8) {  // float64 patches with a common fraction > 0: two launches per iteration on strips (srx_stile.hpp)
+        if (impl == IMPL_STILE)
+            return stile::iterate<T>(hr_init, hr, B, N, f, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, n_iter, step, scale, errors, st);
+    }
     if (impl == IMPL_CTILE)
         return ctile::iterate<T>(hr_init, hr, B, N, py, px, kc, kt, Mg, Cg, Mu, ncu, nyx, NS, NB, Vtot, ar, H, W, n_iter, step, scale, errors, st);
     if constexpr (sizeof(T) == 4) {

@@ -711,7 +711,45 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR: the two-launch window kernels
     assert S.last_path() == "atile"
     S.ibp_batched(lr_d[:1].double(), shifts, psf, saa_d[:1].double(), f, 2, 0.5, precision="f64")
+    assert S.last_path() == "stile"                                                         # float64: the strip kernels (srx_stile.hpp)
+    S.ibp_batched(lr_d[:1].double(), shifts, synth.asymmetric_psf(), saa_d[:1].double(), f, 2, 0.5, precision="f64")
     assert S.last_path() == "mosaic"
+
+
+@pytest.mark.parametrize("cfg", sorted(PATCH_CFGS))
+def test_strip_kernels_f64_vs_oracle(cfg):
+    """Round 4: float64 patches with a common fraction > 0 (C2 in the reference's own precision, mono_cal_target/run_sr.py:74) run as two
+    launches per iteration on register-resident strips (k_ibp_sv / k_ibp_sh, srx_stile.hpp) instead of the tile kernels.  Against the oracle
+    after 1, 2, 10 and 80 iterations at the float64 tolerances (HR state 1e-8 DN, MSE trace 1e-10), against the tile kernels, in place, and
+    a batch against its items: full phase grids (byte mosaic + 0/1 count masks), non-integer frames (float64 mosaic), frames sharing a
+    phase (count plane), a half grid (nothing above the image)."""
+    from oracle import sr_oracle as O
+    S.set_precision("f64")
+    try:
+        f, shifts, integer_lr = PATCH_CFGS[cfg]
+        psf, lr, saa = _patch_case(f, shifts, 2, integer_lr)
+        O.set_threads(8)
+        try:
+            for n in (1, 2, 10, 80):
+                hr, errs = S.ibp_batched(lr, shifts, psf, saa, f, n, 0.5)
+                assert S.last_path() == "stile"
+                for i in range(2 if n < 80 else 1):
+                    hr_o, err_o = O.ibp(list(lr[i]), shifts, psf, saa[i], f, n, 0.5)
+                    close(hr[i].cpu().numpy(), hr_o, IBP_TOL["f64"])
+                    np.testing.assert_allclose(errs[i].cpu().numpy(), err_o, rtol=ERR_RTOL["f64"])
+        finally:
+            O.set_threads(1)
+        hr_t, e_t = S.ibp_batched(lr, shifts, psf, saa, f, 80, 0.5, flags=S.FLAG_TILES)
+        assert S.last_path() == "mosaic"
+        assert float((hr - hr_t).abs().max()) < 1e-8
+        np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=1e-10)
+        lr_d, buf = torch.from_numpy(lr).cuda(), torch.from_numpy(saa).cuda()
+        hr2, errs2 = S.ibp_batched(lr_d, shifts, psf, buf, f, 80, 0.5, out=buf)
+        assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
+        one, e1 = S.ibp_batched(lr_d[1:2], shifts, psf, torch.from_numpy(saa[1:2]).cuda(), f, 80, 0.5)
+        assert torch.equal(one[0], hr[1]) and torch.equal(e1[0], errs[1])
+    finally:
+        S.set_precision("f32")
 
 
 def test_patch_tables_from_the_lr_frames_equal_the_plane_route():
