@@ -14,10 +14,11 @@
 //   k_ibp_sh  "horizontal": 64 rows x 256 columns (lane = row, registers = columns, four blocks side by side): stage B -- H-blur,
 //                           H-prefilter + FIR = Y, the near band, G = M - C Y, the MSE sum, H-FIR' + prefilter, H-blur'.
 //
-// Between the two the plane crosses HBM once each way (8 B per pixel and direction), in the layout its READER is coalesced in
-// (k_ibp_sv writes rows, k_ibp_sh writes columns), and each kernel starts with one wave-private transpose (srx_patch.hpp's transpose64 on
-// the low and the high words).  Per HR pixel and iteration: sv reads G' 8 + hr 8, writes hr 8 + Yv 8; sh reads Yv 8 + M 1 (bytes) or 8,
-// writes G' 8 = 49 B against the algorithmic 24 (SURVEY 8d in float64) -- where the tile kernels moved ~150.
+// Between the two ONE plane per patch crosses memory once each way (8 B per pixel and direction), row-major, in place: k_ibp_sv reads and
+// writes its columns of it as they are (lane = column), k_ibp_sh transposes its rows in and out (srx_patch.hpp's wave-private transpose64
+// on the low and the high words).  Per HR pixel and iteration: sv reads G' 8 + hr 8, writes hr 8 + Yv 8; sh reads Yv 8 + M 1 (bytes) or
+// 8, writes G' 8 = 49 B against the algorithmic 24 (SURVEY 8d in float64) -- where the tile kernels moved ~150.  Measured (C2, B = 1024):
+// both kernels run at the memory's pace (sv 2.15 GB in ~340 us, sh 1.14 GB in ~290), VALU time is a fifth of it.
 // The closed forms of SciPy's 12-sample pad, the carry fix-ups between blocks (z^(i+1) * carry over the first FIX samples; FIX = 28 in
 // float64: |z|^29 = 3e-17) and the near band are srx_patch.hpp's, in T.  Row -1 of Y / G (frames with n_k > 0) rides as plane row 0:
 // the planes between the kernels hold row q = gy + ex (the last grid row is empty then, srx_patch.hpp's axis_ok).
@@ -344,7 +345,7 @@ constexpr int OFF_YT = 0, OFF_YL = 4 * YW, OFF_GT = 8 * YW, OFF_GL = 11 * YW, ST
 // =====================================================================================================================================
 template <typename T>
 __global__ void __launch_bounds__(256, 2)
-    k_ibp_sv(const T *__restrict__ hr_in, T *__restrict__ hr, const T *__restrict__ Gh, T *__restrict__ Yv, const AxW<T> aw, int exy, T sn, int mode,
+    k_ibp_sv(const T *__restrict__ hr_in, T *__restrict__ hr, T *P, const AxW<T> aw, int exy, T sn, int mode,
              const double *__restrict__ epart, const double *__restrict__ Vtot, double scale, double *__restrict__ errors, int n_iter, int it_done)
 {
     __shared__ float lds[4 * RW];
@@ -369,24 +370,13 @@ __global__ void __launch_bounds__(256, 2)
     } else {
         if (errors && u == 0 && tid == 0)
             errors[(size_t)b * n_iter + it_done] = (((epart[4 * b] + epart[4 * b + 1]) + (epart[4 * b + 2] + epart[4 * b + 3])) + Vtot[b]) * scale;
-        // G' arrives column-major, Gh[b][column][q], q = gy + exy: read in row layout (lane = row), transpose
-        const __amdgpu_buffer_rsrc_t rs_g = fused::plane_rsrc(Gh + (size_t)b * PN * PN, (size_t)PN * PN);
-        T gtop = 0;
-        if (exy && s == 0)
-            gtop = fused::buf_load<T>(rs_g, (64 * u + lane) * PN * EB, 0);  // G'[-1, column] (one strided load per strip)
-        {
-            T r[64];
-            const int qb = (64 * s + exy + lane) * EB;
+        // G' arrives in the plane this launch writes Yv to, row-major, plane row q = gy + exy (row 256 of the last block: out of range, 0 --
+        // grid row 255 holds no sample when a frame reaches above the grid (axis_ok), G' = 0 there)
+        const __amdgpu_buffer_rsrc_t rs_g = fused::plane_rsrc(P + (size_t)b * PN * PN, (size_t)PN * PN);
 #pragma unroll
-            for (int j = 0; j < 64; j++)
-                r[j] = fused::buf_load<T>(rs_g, qb, (64 * u + j) * PN * EB);
-            transpose64(r, a, lds + s * RW, lane);
-        }
-        if (exy && s == 3)
-            a[63] = 0;  // grid row 255 holds no sample when a frame reaches above the grid (axis_ok): G' = 0 there
-        if (!exy)
-            gtop = a[0];
-        __syncthreads();  // (the transposes ran over the exchange slots of this wave only; the barrier orders them before the neighbours' reads below)
+        for (int i = 0; i < 64; i++)
+            a[i] = fused::buf_load<T>(rs_g, colb, rowb + (i + exy) * PN * EB);
+        const T gtop = exy ? (s == 0 ? fused::buf_load<T>(rs_g, colb, 0) : (T)0) : a[0];
         Rown[S0 + lane] = a[0];
         Rown[S0 + 64 + lane] = a[1];
         Rown[S0 + 128 + lane] = a[63];
@@ -417,7 +407,7 @@ __global__ void __launch_bounds__(256, 2)
     blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, S0, lane, aw.kb);
     T yex = 0;
     fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, S1, S0, lane, aw.wf, yex);
-    const __amdgpu_buffer_rsrc_t rs_y = fused::plane_rsrc(Yv + (size_t)b * PN * PN, (size_t)PN * PN);
+    const __amdgpu_buffer_rsrc_t rs_y = fused::plane_rsrc(P + (size_t)b * PN * PN, (size_t)PN * PN);
 #pragma unroll
     for (int i = 0; i < 64; i++)
         if (!(exy && s == 3 && i == 63))
@@ -431,14 +421,18 @@ __global__ void __launch_bounds__(256, 2)
 // =====================================================================================================================================
 template <typename T, bool C01, bool M8>
 __global__ void __launch_bounds__(256, 2)
-    k_ibp_sh(const T *__restrict__ Yv, T *__restrict__ Gh, const STabs<T> tb, const patch::PatchArgs pa, const AxW<T> aw, double *__restrict__ epart,
+    k_ibp_sh(T *P, const STabs<T> tb, const patch::PatchArgs pa, const AxW<T> aw, double *__restrict__ epart,
              int want_err)
 {
     __shared__ float lds[4 * RW + STRIP_T * (sizeof(T) / 4) + 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.x, b = blockIdx.y;
+    // the LR mosaic as bytes when every far-field sample of the patch is an integer in [0, 255] (k_stile_prep's flag), else as T: two
+    // instantiations launched one after the other, a patch is taken by exactly one (as a run-time choice inside one kernel -- even per
+    // group of eight columns, feeding the same arithmetic -- the allocator spilled 92 registers where either form alone spills 4)
     if ((__builtin_amdgcn_readfirstlane(tb.m8[b]) != 0) != M8)
         return;
+    constexpr bool m8 = M8;
     T *Rown = reinterpret_cast<T *>(lds + u * RW);
     const T *Rlf = reinterpret_cast<const T *>(lds + (u - 1) * RW), *Rrt = reinterpret_cast<const T *>(lds + (u + 1) * RW);
     T *strips = reinterpret_cast<T *>(lds + 4 * RW);
@@ -452,17 +446,48 @@ __global__ void __launch_bounds__(256, 2)
     T r[64];
     {
         T a[64];
-        const __amdgpu_buffer_rsrc_t rs_y = fused::plane_rsrc(Yv + (size_t)b * PN * PN, (size_t)PN * PN);
+        const __amdgpu_buffer_rsrc_t rs_y = fused::plane_rsrc(P + (size_t)b * PN * PN, (size_t)PN * PN);
         const int colb = (64 * u + lane) * EB;
 #pragma unroll
         for (int i = 0; i < 64; i++)
             a[i] = fused::buf_load<T>(rs_y, colb, (64 * s + i) * PN * EB);
         transpose64(a, r, lds + u * RW, lane);
     }
-    __syncthreads();
     blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, S0, lane, aw.kb);
     T yexx = 0;  // Y[gy, -1] (u == 0)
     fwd_chain(r, u == 0, u == 3, Rown, Rlf, Rrt, S1, S0, lane, aw.wf, yexx);
+    // ---- requested here, consumed behind the strips' barrier: the byte mosaic of the G step and this thread's near-band descriptors.  This strip's
+    // share of srx_patch.hpp's enumeration: the top rows (strip 0 only: at most 3 x 257 pixels, four per thread) and the left columns of its
+    // own rows (at most 4 x 64, one per thread).  (As loads inside the near-band loop they were three dependent round trips per pixel and
+    // strip 0 took twice as long as its neighbours.)
+    unsigned m8w[16];
+    if (m8) {
+        const __amdgpu_buffer_rsrc_t rsM8 = fused::plane_rsrc(tb.Mt8 + (size_t)b * (PN / 4) * PN, (size_t)(PN / 4) * PN);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const patch::u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsM8, ((4 * u + g) * PN + gy) * 16, 0, 0);
+            m8w[4 * g] = v.x, m8w[4 * g + 1] = v.y, m8w[4 * g + 2] = v.z, m8w[4 * g + 3] = v.w;
+        }
+    }
+    constexpr int NQ = 5;
+    int nt[NQ];
+    bool non[NQ];
+    uint2 nr[NQ], ne[NQ];
+    T2<T> nm[NQ];
+    {
+        const int WN = PN + exx, LN = exx + nbx, ntop = (exy + nby) * WN;
+        const int gy_lo = max(nby, 64 * s - exy), gy_hi = min(PN - exy, 64 * s + 64 - exy);
+#pragma unroll
+        for (int k = 0; k < NQ - 1; k++)
+            nt[k] = tid + 256 * k, non[k] = s == 0 && nt[k] < ntop;
+        nt[NQ - 1] = ntop + (gy_lo - nby) * LN + tid, non[NQ - 1] = gy_hi > gy_lo && nt[NQ - 1] < ntop + (gy_hi - nby) * LN;
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+            nr[k] = ne[k] = make_uint2(0, 0), nm[k] = T2<T>{0, 0};
+            if (non[k])
+                nr[k] = tb.nrec[nt[k]], ne[k] = tb.nent[nt[k]], nm[k] = tb.Mn[(size_t)b * NN_PAD + nt[k]];
+        }
+    }
     // ---- near-band strips of Y
     if (s == 0 && q <= nby + exy) {
         T *dst = Yt + q * YW + 64 * u + exx;
@@ -482,35 +507,26 @@ __global__ void __launch_bounds__(256, 2)
             dst[-1] = yexx;
     }
     __syncthreads();
-    // ---- near band: G = M - the listed Y samples; the counted samples' share of the MSE trace.  This strip's share of srx_patch.hpp's
-    // enumeration: the top rows (strip 0), and the left columns of its own rows
+    // ---- near band: G = M - the listed Y samples; the counted samples' share of the MSE trace
     T sq = 0;
-    {
-        const int WN = PN + exx, LN = exx + nbx, ntop = (exy + nby) * WN;
-        const int gy_lo = max(nby, 64 * s - exy), gy_hi = min(PN - exy, 64 * s + 64 - exy);
-        auto near_px = [&](int t) {
-            const uint2 nr = tb.nrec[t];
-            const T2<T> nm = tb.Mn[(size_t)b * NN_PAD + t];
-            const int cnt = nr.x & 255, cu = (nr.x >> 8) & 255, dst = nr.x >> 16;
-            T ys = 0;
-            for (int g = 0; 4 * g < cnt; g++) {
-                const uint2 e = tb.nent[(size_t)g * NN_PAD + t];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        if (non[k]) {
+            const int cnt = nr[k].x & 255, cu = (nr[k].x >> 8) & 255, dst = nr[k].x >> 16;
+            T ys = (cnt > 0 ? strips[ne[k].x & 0xffff] : (T)0) + (cnt > 1 ? strips[ne[k].x >> 16] : (T)0) + (cnt > 2 ? strips[ne[k].y & 0xffff] : (T)0) +
+                   (cnt > 3 ? strips[ne[k].y >> 16] : (T)0);
+            for (int g = 1; 4 * g < cnt; g++) {  // more than four frames on a pixel: the corner, or frames sharing a phase
+                const uint2 e = tb.nent[(size_t)g * NN_PAD + nt[k]];
                 const int c = cnt - 4 * g;
                 ys += (c > 0 ? strips[e.x & 0xffff] : (T)0) + (c > 1 ? strips[e.x >> 16] : (T)0) + (c > 2 ? strips[e.y & 0xffff] : (T)0) +
                       (c > 3 ? strips[e.y >> 16] : (T)0);
             }
-            Gt[dst] = nm.x - ys;
+            Gt[dst] = nm[k].x - ys;
             if (cu > 0) {
-                const T gu = nm.y - (T)cu * strips[nr.y];
+                const T gu = nm[k].y - (T)cu * strips[nr[k].y];
                 sq += gu * gu / (T)cu;
             }
-        };
-        if (s == 0)
-            for (int t = tid; t < ntop; t += 256)
-                near_px(t);
-        if (gy_hi > gy_lo)
-            for (int t = ntop + (gy_lo - nby) * LN + tid; t < ntop + (gy_hi - nby) * LN; t += 256)
-                near_px(t);
+        }
     }
     __syncthreads();
     // ---- G = M - C Y on the grid; near-band pixels take their value from the strips
@@ -525,54 +541,31 @@ __global__ void __launch_bounds__(256, 2)
             crow = (T)((rm >> (gyc & 63)) & 1ull);
         }
         const __amdgpu_buffer_rsrc_t rsC = fused::plane_rsrc(tb.Ct, (size_t)PN * PN);
+        const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(tb.Mt + (size_t)b * PN * PN, (size_t)PN * PN);
         const int tbl = ((16 * u * PN + gy) * 4) * EB;  // (column quad 16 u, row gy) of the transposed planes, bytes
-        if (M8) {
-            const __amdgpu_buffer_rsrc_t rsM8 = fused::plane_rsrc(tb.Mt8 + (size_t)b * (PN / 4) * PN, (size_t)(PN / 4) * PN);
-            unsigned m8w[16];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const patch::u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsM8, ((4 * u + g) * PN + gy) * 16, 0, 0);
-                m8w[4 * g] = v.x, m8w[4 * g + 1] = v.y, m8w[4 * g + 2] = v.z, m8w[4 * g + 3] = v.w;
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+            T mv[8], cv[8];
+            if (m8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    mv[j] = (T)((m8w[(j0 + j) >> 2] >> (8 * ((j0 + j) & 3))) & 255u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    mv[j] = fused::buf_load<T>(rsM, tbl + (((j0 + j) >> 2) * PN * 4 + ((j0 + j) & 3)) * EB, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 64; j++) {
-                const T mv = (T)((m8w[j >> 2] >> (8 * (j & 3))) & 255u);
-                T g, w;
-                if (C01) {
-                    const bool on = (cm >> j) & 1ull;
-                    g = on ? fma(-crow, r[j], mv) : (T)0;
-                    w = 1;
-                } else {
-                    const T cv = fused::buf_load<T>(rsC, tbl + ((j >> 2) * PN * 4 + (j & 3)) * EB, 0);
-                    g = fma(-cv, r[j], mv);
-                    w = mosaic::rcp_count(cv);
-                }
-                const T g2 = g * g * w;
+            for (int j = 0; j < 8; j++)
+                cv[j] = C01 ? (((cm >> (j0 + j)) & 1ull) ? crow : (T)0) : fused::buf_load<T>(rsC, tbl + (((j0 + j) >> 2) * PN * 4 + ((j0 + j) & 3)) * EB, 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const T g = fma(-cv[j], r[j0 + j], mv[j]);
+                const T g2 = g * g * (C01 ? (T)1 : mosaic::rcp_count(cv[j]));
                 sqf += g2;
-                if (j < 3)
-                    gn[j] = g2;
-                r[j] = g;
-            }
-        } else {
-            const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(tb.Mt + (size_t)b * PN * PN, (size_t)PN * PN);
-#pragma unroll
-            for (int j0 = 0; j0 < 64; j0 += 8) {
-                T mv[8], cv[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int o = tbl + (((j0 + j) >> 2) * PN * 4 + ((j0 + j) & 3)) * EB;
-                    mv[j] = fused::buf_load<T>(rsM, o, 0);
-                    cv[j] = C01 ? (((cm >> (j0 + j)) & 1ull) ? crow : (T)0) : fused::buf_load<T>(rsC, o, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const T g = fma(-cv[j], r[j0 + j], mv[j]);
-                    const T g2 = g * g * (C01 ? (T)1 : mosaic::rcp_count(cv[j]));
-                    sqf += g2;
-                    if (j0 + j < 3)
-                        gn[j0 + j] = g2;
-                    r[j0 + j] = g;
-                }
+                if (j0 + j < 3)
+                    gn[j0 + j] = g2;
+                r[j0 + j] = g;
             }
         }
         if (u == 0)
@@ -611,11 +604,17 @@ __global__ void __launch_bounds__(256, 2)
     const T gm1 = u == 0 ? gtop : Rlf[S1 + 128 + lane];
     const T gp1 = u == 3 ? (T)0 : Rrt[S1 + lane], gp2 = u == 3 ? (T)0 : Rrt[S1 + 64 + lane];
     bwd_chain(r, u == 0, u == 3, Rown, Rlf, Rrt, S0 + 384, S0, lane, aw.wb, aw.kt, gm1, gp1, gp2, gtop, [](int) {}, [](int, T v) { return v; });
-    // column-major for k_ibp_sv: Gh[b][column][q]
-    const __amdgpu_buffer_rsrc_t rs_g = fused::plane_rsrc(Gh + (size_t)b * PN * PN, (size_t)PN * PN);
+    // back to the plane, over this strip's own rows, row-major (k_ibp_sv reads columns of it): the second transpose
+    __syncthreads();  // the neighbours have read this wave's exchange slots, which the transpose runs over
+    {
+        T a[64];
+        transpose64(r, a, lds + u * RW, lane);
+        const __amdgpu_buffer_rsrc_t rs_g = fused::plane_rsrc(P + (size_t)b * PN * PN, (size_t)PN * PN);
+        const int colb = (64 * u + lane) * EB;
 #pragma unroll
-    for (int j = 0; j < 64; j++)
-        fused::buf_store<T>(r[j], rs_g, q * EB, (64 * u + j) * PN * EB);
+        for (int i = 0; i < 64; i++)
+            fused::buf_store<T>(a[i], rs_g, colb, (64 * s + i) * PN * EB);
+    }
 }
 
 // ---- host --------------------------------------------------------------------------------------------------------------------------
@@ -640,7 +639,7 @@ template <typename T> static inline void fill_axis(const mosaic::AxisPlan &pl, i
 static inline size_t tabs_bytes(int eb, int B, int N)
 {
     const size_t ngrp = ((size_t)N + 3) / 4, plane = (size_t)B * PN * PN * eb;
-    return 3 * align_up(plane) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * eb) + align_up((size_t)NN_PAD * 8) +
+    return 2 * align_up(plane) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * eb) + align_up((size_t)NN_PAD * 8) +
            align_up(ngrp * NN_PAD * 8) + align_up((size_t)B * NN_PAD * 2 * eb) + align_up((size_t)B * 4 * sizeof(double));
 }
 
@@ -650,7 +649,7 @@ static int iterate(const T *hr_init, T *hr, int B, int N, int f, const mosaic::A
                    Arena &ar, int n_iter, double step, double scale, double *errors, hipStream_t st)
 {
     const int Hg = PN + 27, Wg = PN + 27, ngrp = NS / 4;
-    T *Mt = ar.take<T>((size_t)B * PN * PN), *Yv = ar.take<T>((size_t)B * PN * PN), *Gh = ar.take<T>((size_t)B * PN * PN);
+    T *Mt = ar.take<T>((size_t)B * PN * PN), *P = ar.take<T>((size_t)B * PN * PN);
     unsigned *Mt8 = ar.take<unsigned>((size_t)B * (PN / 4) * PN);
     int *m8 = ar.take<int>(B);
     T *Ct = ar.take<T>((size_t)PN * PN);
@@ -682,21 +681,31 @@ static int iterate(const T *hr_init, T *hr, int B, int N, int f, const mosaic::A
                            Mn);
         SRX_CHECK_LAUNCH();
     }
-    const STabs<T> tb{Mt, Mt8, m8, Ct, nrec, nent, Mn};
     const T sn = (T)(step / (double)N);
-    const dim3 grid(4, B), blk(256);
     const int want = errors ? 1 : 0;
-    SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr_init, hr, Gh, Yv, awy, pa.y.ex, sn, 1, epart, Vtot, scale, errors, n_iter, 0);
-    for (int it = 0; it < n_iter; it++) {
-        // both mosaic forms over the whole batch: every patch is taken by exactly one of the two launches (m8)
-        if (pa.c01) {
-            SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, true>), grid, blk, 0, st, Yv, Gh, tb, pa, awx, epart, want);
-            SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, false>), grid, blk, 0, st, Yv, Gh, tb, pa, awx, epart, want);
-        } else {
-            SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, true>), grid, blk, 0, st, Yv, Gh, tb, pa, awx, epart, want);
-            SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, false>), grid, blk, 0, st, Yv, Gh, tb, pa, awx, epart, want);
+    // The batch in chunks of 128 patches, every launch of a chunk before the next chunk's first: 512 workgroups = one round of the 256
+    // compute units at two workgroups each, and the chunk's working set (state, plane, byte mosaic: 1.06 MB per patch) stays in the 256 MB
+    // Infinity Cache between a launch and the next (C2, 1024 patches: 63.8 -> 58.1 ms per step; 64: 73, launch-bound; 192 / 256: 59 / 61).
+    constexpr int CB = 128;
+    for (int c0 = 0; c0 < B; c0 += CB) {
+        const int nb = std::min(CB, B - c0);
+        const size_t po = (size_t)c0 * PN * PN;
+        const STabs<T> tb{Mt + po, Mt8 + (size_t)c0 * (PN / 4) * PN, m8 + c0, Ct, nrec, nent, Mn + (size_t)c0 * NN_PAD};
+        double *ep = epart + 4 * c0, *er = errors ? errors + (size_t)c0 * n_iter : nullptr;
+        const double *vt = Vtot + c0;
+        const dim3 grid(4, nb), blk(256);
+        SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr_init + po, hr + po, P + po, awy, pa.y.ex, sn, 1, ep, vt, scale, er, n_iter, 0);
+        for (int it = 0; it < n_iter; it++) {
+            if (pa.c01) {
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, true>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, false>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
+            } else {
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, true>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, false>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
+            }
+            SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr + po, hr + po, P + po, awy, pa.y.ex, sn, it == n_iter - 1 ? 2 : 0, ep, vt, scale, er,
+                       n_iter, it);
         }
-        SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr, hr, Gh, Yv, awy, pa.y.ex, sn, it == n_iter - 1 ? 2 : 0, epart, Vtot, scale, errors, n_iter, it);
     }
     return SRX_OK;
 }
