@@ -64,3 +64,23 @@ def test_oracle_interleave4_is_a_pixel_shuffle():
     assert np.array_equal(out[3::2, 0::2], fr[1][1:])                # (0, +1): rows 2i+1
     assert np.array_equal(out[3::2, 1:-1:2], fr[2][1:, 1:])          # (-1, +1): rows 2i+1, columns 2j-1
     assert np.array_equal(out[0::2, 1:-1:2], fr[3][:, 1:])           # (-1, 0)
+
+
+def test_png_writer_round_trips(tmp_path):
+    """session.write_png_u8 (Up filter + one zlib pass, instead of PIL's per-row filter search): the file is a valid 8-bit greyscale
+    PNG whose pixels read back exactly -- smooth, noisy and constant images, odd sizes, one row / one column."""
+    from PIL import Image
+    from sr_mi355x import session
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:97, 0:131]
+    cases = [((np.sin(yy / 9.0) * np.cos(xx / 7.0) * 120 + 128).astype(np.uint8)), rng.integers(0, 256, (64, 33), dtype=np.uint8),
+             np.full((5, 7), 255, np.uint8), np.zeros((1, 40), np.uint8), rng.integers(0, 256, (40, 1), dtype=np.uint8)]
+    for i, a in enumerate(cases):
+        path = str(tmp_path / f"t{i}.png")
+        session.write_png_u8(path, a)
+        im = Image.open(path)
+        assert im.mode == "L" and im.size == (a.shape[1], a.shape[0])
+        assert np.array_equal(np.array(im), a)
+    rgb = rng.integers(0, 256, (6, 5, 3), dtype=np.uint8)  # not a greyscale plane: PIL writes it
+    session.write_png_u8(str(tmp_path / "rgb.png"), rgb)
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "rgb.png"))), rgb)
