@@ -21,7 +21,20 @@
 namespace srx {
 namespace ctile {
 
-constexpr int RG = 256, RGY = 64, HALO = 6, VT = RG - 2 * HALO, VTY = RGY - 2 * HALO, SW = 4;
+constexpr int RG = 256, HALO = 6, VT = RG - 2 * HALO, SW = 4;
+// Rows of a tile's region.  float32: 64 (52 owned).  float64: a region of 64 rows is 128 registers and the pre-update state cannot be
+// held beside it -- the first float64 form read it AGAIN behind the last blur (eight dependent batches of loads at the end of every
+// tile: 55 % of the wave-cycles waiting, 58 spilled registers, 1.63x the algorithmic traffic).  With SRX_CTILE_ROWS64 = 40 rows (28
+// owned) region and held state are 2 x 80 registers: 1.50x halo reads instead of 1.29x + the re-read, no second load phase, no spill.
+// mono_cal_target's shape, us per iteration on one box: 64 rows 115; 48 rows 106.6 (45 spilled); 44: 99.9; 40: 92.2; 36: 94.0; 32: 96.8.
+#ifndef SRX_CTILE_ROWS64
+#define SRX_CTILE_ROWS64 40
+#endif
+template <typename T> struct Rows {
+    static constexpr int NR = sizeof(T) == 8 ? SRX_CTILE_ROWS64 : 64;
+};
+static_assert(SRX_CTILE_ROWS64 % 4 == 0 && SRX_CTILE_ROWS64 > 2 * HALO && SRX_CTILE_ROWS64 <= 64, "row quads; something to own");
+static inline int rows_for(int eb) { return eb == 8 ? SRX_CTILE_ROWS64 : 64; }
 
 struct CArgs {
     int H, W, tiles_x, tiles_y, HP, WP;
@@ -45,9 +58,11 @@ template <typename T> struct CTabs {
 };
 
 // LDS (in elements of T): per wave two sets of edge slots [64 rows][4] for its three left / right edge columns, then the near-band strips
-constexpr int EDGE = 64 * 4, WSLOT = 4 * EDGE;  // per wave: set 0 {left, right}, set 1 {left, right}
-constexpr int OFF_YT = 4 * WSLOT, OFF_GT = OFF_YT + SW * RG, OFF_YL = OFF_GT + SW * RG, OFF_GL = OFF_YL + RGY * SW, OFF_ZERO = OFF_GL + RGY * SW,
-              LDS_T = OFF_ZERO + 4;
+template <int NR> struct Lds {
+    static constexpr int EDGE = NR * 4, WSLOT = 4 * EDGE;  // per wave: set 0 {left, right}, set 1 {left, right}
+    static constexpr int OFF_YT = 4 * WSLOT, OFF_GT = OFF_YT + SW * RG, OFF_YL = OFF_GT + SW * RG, OFF_GL = OFF_YL + NR * SW, OFF_ZERO = OFF_GL + NR * SW,
+                         LDS_T = OFF_ZERO + 4;
+};
 
 static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
 {
@@ -180,13 +195,13 @@ __device__ __forceinline__ double shift_dn(double v, double fill)
 
 // 7-tap correlation down the columns, in registers, zero beyond the region's rows (those outputs are outside every dependency cone
 // that ends in a stored pixel)
-template <typename T> __device__ __forceinline__ void blur_rows(T (&a)[64], const T *__restrict__ k)
+template <typename T, int NR> __device__ __forceinline__ void blur_rows(T (&a)[NR], const T *__restrict__ k)
 {
     const T k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3], k4 = k[4], k5 = k[5], k6 = k[6];
     T p0 = 0, p1 = 0, p2 = 0;  // the three ORIGINAL samples above the current row
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const T c = a[i], n1 = i + 1 < 64 ? a[i + 1] : (T)0, n2 = i + 2 < 64 ? a[i + 2] : (T)0, n3 = i + 3 < 64 ? a[i + 3] : (T)0;
+    for (int i = 0; i < NR; i++) {
+        const T c = a[i], n1 = i + 1 < NR ? a[i + 1] : (T)0, n2 = i + 2 < NR ? a[i + 2] : (T)0, n3 = i + 3 < NR ? a[i + 3] : (T)0;
         a[i] = k0 * p0 + k1 * p1 + k2 * p2 + k3 * c + k4 * n1 + k5 * n2 + k6 * n3;
         p0 = p1, p1 = p2, p2 = c;
         if ((i & 7) == 7)
@@ -197,18 +212,29 @@ template <typename T> __device__ __forceinline__ void blur_rows(T (&a)[64], cons
 // 7-tap correlation along the rows = along the LANES.  Every wave first publishes its three left / right edge columns (slots of set
 // `set`: the two blurs of an iteration alternate, so no wave overwrites what a neighbour may still read); a row's six shifted copies
 // then pull the neighbour wave's samples in at the wave's ends (zero at the region's ends).  One workgroup barrier.
-template <typename T>
-__device__ __forceinline__ void blur_lanes(T (&a)[64], int u, int set, T *lds, int lane, const T *__restrict__ k)
+//
+// Round 4, measured (tools/dev/ct_stamps.py, tools/microbench/lane_shift_cost.hip): the two lane blurs are 28 K of a float64 tile's 49 K
+// cycles, ~350 cycles per row -- a DPP move costs a wave ~13 cycles (v_fma_f64: 5 alone, 7 with a second wave on the SIMD), and a row
+// needs 24 of them.  Two other forms were built and measured on the same box against this one's 92.6 us per iteration (3072 x 4096):
+//   * the window from a wave-private LDS image of the row ([3 | 64 | 3] samples, four rows at a time: one store, the halo copied in by the
+//     edge lanes, six 8-byte reads at lane + 0 .. lane + 6): 123 us at 40 rows (35 spilled registers), 103 us at 32 -- ten LDS
+//     instructions of 512 bytes per row and wave, eight waves per compute unit: the LDS's 128 bytes per cycle bound it at the same ~400
+//     cycles per row;
+//   * the shifts' fill values read where they are used (lane 0 reads the left neighbour's samples, the others the right one's: two LDS
+//     reads per row instead of six broadcasts): 129 us (the selects and the 16-byte read cost more registers than the reads saved time).
+template <typename T, int NR>
+__device__ __forceinline__ void blur_lanes(T (&a)[NR], int u, int set, T *lds, int lane, const T *__restrict__ k)
 {
+    constexpr int EDGE = Lds<NR>::EDGE, WSLOT = Lds<NR>::WSLOT, OFF_ZERO = Lds<NR>::OFF_ZERO;
     T *L = lds + u * WSLOT + set * 2 * EDGE, *R = L + EDGE;
     if (lane < 3) {
 #pragma unroll
-        for (int i = 0; i < 64; i++)
+        for (int i = 0; i < NR; i++)
             L[i * 4 + lane] = a[i];
     }
     if (lane >= 61) {
 #pragma unroll
-        for (int i = 0; i < 64; i++)
+        for (int i = 0; i < NR; i++)
             R[i * 4 + lane - 61] = a[i];
     }
     const T k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3], k4 = k[4], k5 = k[5], k6 = k[6];
@@ -220,7 +246,7 @@ __device__ __forceinline__ void blur_lanes(T (&a)[64], int u, int set, T *lds, i
     const T *nr = u < 3 ? lds + (u + 1) * WSLOT + set * 2 * EDGE : lds + OFF_ZERO;
     const int sl = u > 0 ? 4 : 0, sr = u < 3 ? 4 : 0;
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
+    for (int i = 0; i < NR; i++) {
         const T l0 = nl[i * sl], l1 = nl[i * sl + 1], l2 = nl[i * sl + 2], r0 = nr[i * sr], r1 = nr[i * sr + 1], r2 = nr[i * sr + 2];
         const T c = a[i];
         const T s1 = shift_up(c, l2), s2 = shift_up(s1, l1), s3 = shift_up(s2, l0);
@@ -271,9 +297,11 @@ __global__ void __launch_bounds__(256, 2)
     k_ibp_ctile(const T *__restrict__ hr_src, T *__restrict__ hr_dst, CTabs<T> tb, CArgs ca, double *__restrict__ epart, const double *__restrict__ eprev,
                 const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
 {
-    constexpr bool HOLD = sizeof(T) == 4;  // float32 keeps the pre-update state in 64 more registers; float64 reads it again
+    constexpr int NR = Rows<T>::NR, VTY = NR - 2 * HALO;
+    constexpr bool HOLD = sizeof(T) == 4 || NR < 64;  // the pre-update state in NR more registers; a float64 region of 64 rows reads it again
     constexpr int EB = (int)sizeof(T);
-    __shared__ T lds[LDS_T];
+    constexpr int OFF_YT = Lds<NR>::OFF_YT, OFF_GT = Lds<NR>::OFF_GT, OFF_YL = Lds<NR>::OFF_YL, OFF_GL = Lds<NR>::OFF_GL, OFF_ZERO = Lds<NR>::OFF_ZERO;
+    __shared__ T lds[Lds<NR>::LDS_T];
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -296,20 +324,24 @@ __global__ void __launch_bounds__(256, 2)
     const int cc = 64 * u + lane;                 // region column of this lane
     const int vc0 = (pc0 + cc) * 2 * EB;          // byte offset of the lane's column inside a row pair
     const int sr0 = (pr0 >> 1) * WP * 2 * EB;     // ... of the region's first row pair
-    T a[64];
+    SRX_PSTAMP(0);
+    T a[NR];
 #pragma unroll
-    for (int k = 0; k < 32; k++)
+    for (int k = 0; k < NR / 2; k++)
         load_pair<T>(rs_src, vc0, sr0 + k * WP * 2 * EB, a[2 * k], a[2 * k + 1]);
-    T hold[HOLD ? 64 : 1];
+    T hold[HOLD ? NR : 1];
     if constexpr (HOLD) {
 #pragma unroll
-        for (int i = 0; i < 64; i++)
+        for (int i = 0; i < NR; i++)
             hold[i] = a[i];
     }
     // the packed operands of the G step: in float32 all sixteen row quads are in flight during the first two blurs; float64 has no
     // registers to spare (the region alone is 128) and fetches them four quads at a time inside the G step
     const int cmok = __builtin_amdgcn_readfirstlane(tb.cmok[b]);
-    constexpr int CMQ = HOLD ? 16 : 4;
+#ifndef SRX_CTILE_CMQ64
+#define SRX_CTILE_CMQ64 4
+#endif
+    constexpr int CMQ = sizeof(T) == 4 ? NR / 4 : (SRX_CTILE_CMQ64 == 0 ? NR / 4 : SRX_CTILE_CMQ64);
     uint2 cm[CMQ];
     const size_t cplane = (size_t)(HP / 4) * WP;
     const __amdgpu_buffer_rsrc_t rsP = fused::plane_rsrc(tb.CM4 + (size_t)b * cplane, cplane);
@@ -320,10 +352,12 @@ __global__ void __launch_bounds__(256, 2)
             cm[q] = make_uint2(v.x, v.y);
         }
     };
-    if (cmok && HOLD)
+    if (cmok && CMQ == NR / 4)
         ldcm(0);
-    blur_rows<T>(a, tb.kw);
-    blur_lanes<T>(a, u, 0, lds, lane, tb.kw + 8);
+    blur_rows<T, NR>(a, tb.kw);
+    SRX_PSTAMP(1);
+    blur_lanes<T, NR>(a, u, 0, lds, lane, tb.kw + 8);
+    SRX_PSTAMP(2);
     double sq = 0.0;
     // ---- near band (tiles on the top / left image edge): strips of b, the listed sums, strips of G
     if (top || left) {
@@ -335,13 +369,13 @@ __global__ void __launch_bounds__(256, 2)
         }
         if (left && u == 0 && cc >= HALO && cc <= HALO + ca.nbx) {
 #pragma unroll
-            for (int i = 0; i < 64; i++)
+            for (int i = 0; i < NR; i++)
                 Yl[i * SW + cc - HALO] = a[i];
         }
         __syncthreads();
     }
     if (top || left) {
-        const int ntop = top ? (ca.exy + ca.nby) * RG : 0, nleft = left ? RGY * ca.LN : 0;
+        const int ntop = top ? (ca.exy + ca.nby) * RG : 0, nleft = left ? NR * ca.LN : 0;
         const int NT = ca.TOPN + (H - ca.nby) * ca.LN, gx0 = pc0 - HALO;
         for (int t = tid; t < ntop + nleft; t += 256) {
             int ngy, ngx;
@@ -382,6 +416,7 @@ __global__ void __launch_bounds__(256, 2)
         }
         __syncthreads();
     }
+    SRX_PSTAMP(3);
     // ---- G = M - C b.  Outside the image the padded operands are zero: G = 0 there, what the adjoint blur must see
     {
         const __amdgpu_buffer_rsrc_t rsM = fused::plane_rsrc(tb.Mp + (size_t)b * oplane, oplane);
@@ -391,10 +426,10 @@ __global__ void __launch_bounds__(256, 2)
         // region columns 6 .. 249 right of the near-band columns (per lane)
         const bool colown = cc >= HALO + (left ? ca.nbx : 0) && cc < RG - HALO;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < NR / 4; q++) {
             T mv[4], cv[4];
             if (cmok) {
-                if (!HOLD && (q % CMQ) == 0)
+                if (CMQ != NR / 4 && (q % CMQ) == 0)
                     ldcm(q);
                 const unsigned w[4] = {cm[q % CMQ].x & 0xffffu, cm[q % CMQ].x >> 16, cm[q % CMQ].y & 0xffffu, cm[q % CMQ].y >> 16};
 #pragma unroll
@@ -411,15 +446,16 @@ __global__ void __launch_bounds__(256, 2)
             for (int r = 0; r < 4; r++) {
                 const int i = 4 * q + r, gy = pr0 + i - HALO;
                 const T g = mv[r] - cv[r] * a[i];
-                const bool rowown = i >= HALO && i < RGY - HALO && gy < H && gy >= (top ? ca.nby : 0);  // wave-uniform
+                const bool rowown = i >= HALO && i < NR - HALO && gy < H && gy >= (top ? ca.nby : 0);  // wave-uniform
                 sqf += rowown ? g * g * mosaic::rcp_count(cv[r]) : (T)0;
                 a[i] = g;
             }
-            if (!HOLD)  // float64: keep each quad's arithmetic where it is (sunk towards the next blur it spilled 18 values)
+            if (sizeof(T) == 8)  // float64: keep each quad's arithmetic where it is (sunk towards the next blur it spilled 18 values)
                 asm volatile("" : "+v"(a[4 * q]), "+v"(a[4 * q + 1]), "+v"(a[4 * q + 2]), "+v"(a[4 * q + 3]));
         }
         sq += colown ? (double)sqf : 0.0;
     }
+    SRX_PSTAMP(4);
     // near-band rows / columns take G from the strips
     if (top) {
 #pragma unroll
@@ -429,7 +465,7 @@ __global__ void __launch_bounds__(256, 2)
     }
     if (left && u == 0 && cc >= HALO && cc < HALO + ca.nbx) {
 #pragma unroll
-        for (int i = 0; i < 64; i++) {
+        for (int i = 0; i < NR; i++) {
             const int gy = pr0 + i - HALO;
             if (gy >= (top ? ca.nby : 0) && gy < H)
                 a[i] = Gl[i * SW + ca.exx + cc - HALO];
@@ -440,19 +476,21 @@ __global__ void __launch_bounds__(256, 2)
         if (lane == 0)
             part[u] = ws;
     }
-    blur_lanes<T>(a, u, 1, lds, lane, tb.kw + 24);  // (its barrier also publishes part[])
+    blur_lanes<T, NR>(a, u, 1, lds, lane, tb.kw + 24);  // (its barrier also publishes part[])
+    SRX_PSTAMP(5);
     if (epart && tid == 0)
         epart[((size_t)b * ca.tiles_y + ty) * ca.tiles_x + tx] = (part[0] + part[1]) + (part[2] + part[3]);
-    blur_rows<T>(a, tb.kw + 16);
+    blur_rows<T, NR>(a, tb.kw + 16);
+    SRX_PSTAMP(6);
     // ---- update and store.  Row pairs this tile does not own go to the plane's trash pair, columns it does not own beyond the buffer
     const T sn = (T)ca.sn;
     if constexpr (HOLD) {
 #pragma unroll
-        for (int i = 0; i < 64; i++)
+        for (int i = 0; i < NR; i++)
             a[i] = clip255<T>(a[i] * sn + hold[i]);
     } else {
 #pragma unroll
-        for (int k0 = 0; k0 < 32; k0 += 4) {
+        for (int k0 = 0; k0 < NR / 2; k0 += 4) {
             T ov[8];
             // the old state, four row pairs at a time; the address passes through an asm that takes the batch's first blurred row, or
             // all 32 loads are hoisted above the last blur (pure reads) and seven of them spill
@@ -467,22 +505,25 @@ __global__ void __launch_bounds__(256, 2)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    SRX_PSTAMP(7);
     const bool colst = cc >= HALO && cc < RG - HALO && pc0 + cc - HALO < W;
     const int trash = (HP >> 1) * WP * 2 * EB;
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
+    for (int k = 0; k < NR / 2; k++) {
         const int rw = 2 * k;
-        const bool rok = rw >= HALO && rw < RGY - HALO && pr0 + rw - HALO < H;
+        const bool rok = rw >= HALO && rw < NR - HALO && pr0 + rw - HALO < H;
         const bool in1 = pr0 + rw + 1 - HALO < H;
         const int off = colst ? vc0 + (rok ? sr0 + k * WP * 2 * EB : trash) : 0x7ffffff0;
         store_pair<T>(rs_dst, off, a[2 * k], in1 ? a[2 * k + 1] : (T)0);
     }
+    SRX_PSTAMP(8);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
 static inline size_t tabs_bytes(int eb, int B, int N, int H, int W)
 {
     const size_t ngrp = ((size_t)N + 3) / 4, NT = (size_t)6 * (W + 4) + (size_t)H * 6;
+    const int VTY = rows_for(eb) - 2 * HALO;
     const size_t ty = cdiv(H, VTY), tx = cdiv(W, VT), HP = ty * VTY + 2 * HALO, WP = tx * VT + 2 * HALO;
     return align_up((size_t)B * HP * WP * eb) + 2 * align_up((size_t)B * (HP + 2) * WP * eb) + align_up(HP * WP * eb) +
            align_up((size_t)B * (HP / 4) * WP * 8) + align_up((size_t)B * 4) + align_up(32 * eb) + align_up(NT * 4) + align_up(ngrp * NT * 16) +
@@ -494,6 +535,7 @@ static int iterate(const T *hr_init, T *hr, int B, int N, const mosaic::AxisPlan
                    const fused::Kernel7<T> &kt, const T *Mg, const T *Cg, const T *Mu, const int *ncu, const int *nyx, int NS, int NB,
                    const double *Vtot, Arena &ar, int H, int W, int n_iter, double step, double scale, double *errors, hipStream_t st)
 {
+    constexpr int VTY = Rows<T>::NR - 2 * HALO;
     ztile::ZArgs za;  // the near-band enumeration and its table builder are srx_ztile.hpp's
     za.H = H, za.W = W, za.tiles_x = cdiv(W, VT), za.tiles_y = cdiv(H, VTY);
     za.HP = za.tiles_y * VTY + 2 * HALO, za.WP = za.tiles_x * VT + 2 * HALO;
