@@ -97,6 +97,7 @@ enum KernelId {
     KID_ATILE_NEAR,
     KID_IBP_SV,
     KID_IBP_SH,
+    KID_SAA_SHIFT,
     KID_COUNT
 };
 

@@ -919,11 +919,15 @@ struct FrameOffsets {
     int oy[SRX_MAX_FRAMES], ox[SRX_MAX_FRAMES];
 };
 
-template <typename T, int F> struct SaaCfg {
-    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3;  // region edge (odd, <= 128)
+constexpr int SAA_ACC_TS = 96;  // edge of a W-plane tile of the two-pass form (k_saa_tile<T, F, true>)
+template <typename T, int F, bool ACC = false> struct SaaCfg {
+    static constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = ACC ? SAA_ACC_TS : TS + 2 * R + 3;  // region edge (<= 128)
     static constexpr int PD = (SR + 12) / F + 6;                                          // LR patch edge bound
-    static constexpr int RS = (SR + 3) & ~3;                                              // row pitch of the row-pass image (16-byte reads)
-    static constexpr int NT = (RS / 2 + 3) & ~3;                                          // region columns per half (a multiple of 4)
+    static constexpr int RSB = (SR + 3) & ~3;                                             // region width in whole column quads
+    static constexpr int RS = RSB % 32 == 0 ? RSB + 4 : RSB;                              // row pitch of the row-pass image (16-byte reads).  Not a
+        // multiple of 32 words: in the column pass a wave reads 16 different LR rows at one column, and with a pitch of 96 words they fall on
+        // two groups of banks (the accumulate pass on 96-wide tiles ran at the one-pass kernel's speed with 0.56x its work until the pitch was 100)
+    static constexpr int NT = (RSB / 2 + 3) & ~3;                                         // region columns per half (a multiple of 4)
     static constexpr int PPT = (PD * PD + 255) / 256;                                     // patch elements per thread
 };
 
@@ -932,13 +936,17 @@ template <typename T, int F> struct SaaCfg {
 // frame); row pass, lane = region column with its x tap in registers, rows wave-uniform; column pass, lane = region
 // ROW with its y tap in registers and the columns unrolled, so the four LR rows a lane combines are four base
 // addresses and every LDS read is base + immediate: 4 reads + 4 fma per output, no index arithmetic.  Two barriers.
-template <typename T, int F>
-__global__ void __launch_bounds__(256)
+// ACC (round 4, the two-pass form): the block's region IS a SAA_ACC_TS-square tile of the W plane [H + 27, W + 27] -- no halo, nothing
+// filtered: the accumulated sum goes to `out` (the plane) and k_saa_shift runs the fractional shift on regions of it.  The fused form
+// accumulates (TS + 2 R + 3)^2 samples per TS^2 outputs over all N frames: 2.07x the work in float32 (TS = 64, R = 11), 6.4x in float64
+// (TS = 32, R = 23); the halo now costs one more read of W instead (C2: 1.08 -> ... ms in float32, 7.2 -> ... in float64).
+template <typename T, int F, bool ACC = false>
+__global__ void __launch_bounds__(256, sizeof(T) == 4 && F == 4 ? 4 : 1)  // float32 at x4: four blocks per compute unit (128 registers, 6 spilled; x2 would spill 68)
     k_saa_tile(const T *__restrict__ coef, int N, int h, int w, const AxisTap<T> *__restrict__ zy,
                const AxisTap<T> *__restrict__ zx, FrameOffsets fo, MosaicArgs<T> ma, int H, int W, T inv_n_div,
                T *__restrict__ out)
 {
-    using C = SaaCfg<T, F>;
+    using C = SaaCfg<T, F, ACC>;
     constexpr int R = C::R, TS = C::TS, SR = C::SR, LD = SR, PD = C::PD, NT = C::NT, PPT = C::PPT, RS = C::RS;
     constexpr int ROWS0 = (PD * PD + 3) & ~3;  // the row-pass image starts on a 16-byte boundary (for T = float)
     static_assert(SR <= 128, "two 64-lane chunks per axis");
@@ -953,9 +961,9 @@ __global__ void __launch_bounds__(256)
     int bx, by, b;
     xcd_block(bx, by, b);
     const int r0 = by * TS, c0 = bx * TS;
-    const int pa = max(0, r0 + SRX_NPAD - R), pb = min(Hp, r0 + SRX_NPAD + TS + R);
-    const int qa = max(0, c0 + SRX_NPAD - R), qb = min(Wp, c0 + SRX_NPAD + TS + R);
-    const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;  // W-plane region = v region + 3
+    const int pa = ACC ? by * SR : max(0, r0 + SRX_NPAD - R), pb = ACC ? min(Hp, pa + SR - 3) : min(Hp, r0 + SRX_NPAD + TS + R);
+    const int qa = ACC ? bx * SR : max(0, c0 + SRX_NPAD - R), qb = ACC ? min(Wp, qa + SR - 3) : min(Wp, c0 + SRX_NPAD + TS + R);
+    const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;  // W-plane region = v region + 3 (ACC: rows [pa, pa + SR) of the plane's Hp + 3)
     // row pass: column cc = lane + 64 chunk, LR rows half, half + 2, ...
     // column pass: region row rr = lane + 64 chunk, columns [NT half, NT half + NT)
     const int cc = min(lane + 64 * chunk, ncw - 1), rr = min(lane + 64 * chunk, nrw - 1);  // lanes past the region repeat its edge
@@ -967,19 +975,25 @@ __global__ void __launch_bounds__(256)
         acc[t] = 0;
     // frame k: LR rows/columns its translated window touches (edge clamped = the 12-px pad; mirrored tap indices stay
     // inside [0, h-1]), from the first / last tap of the window
-    int jy0, jx0, npy, npx;
-    auto geometry = [&](int k) {
-        const int oy = fo.oy[k], ox = fo.ox[k];
+    // (for all frames at once, by the first N threads: as four dependent global loads at the top of every frame's fetch they were a
+    // round trip per frame and block that nothing overlapped)
+    __shared__ int geo[SRX_MAX_FRAMES][4];
+    if (tid < N) {
+        const int oy = fo.oy[tid], ox = fo.ox[tid];
         const int y_lo = min(max(pa + oy - SRX_NPAD, 0), H - 1), y_hi = min(max(pa + nrw - 1 + oy - SRX_NPAD, 0), H - 1);
         const int x_lo = min(max(qa + ox - SRX_NPAD, 0), W - 1), x_hi = min(max(qa + ncw - 1 + ox - SRX_NPAD, 0), W - 1);
         const AxisTap<T> ty0 = zy[y_lo], ty1 = zy[y_hi], tx0 = zx[x_lo], tx1 = zx[x_hi];
-        jy0 = min(min(ty0.idx[0], ty0.idx[1]), min(ty0.idx[2], ty0.idx[3]));
-        jx0 = min(min(tx0.idx[0], tx0.idx[1]), min(tx0.idx[2], tx0.idx[3]));
-        npy = max(max(ty1.idx[0], ty1.idx[1]), max(ty1.idx[2], ty1.idx[3])) - jy0 + 1;  // <= PD
-        npx = max(max(tx1.idx[0], tx1.idx[1]), max(tx1.idx[2], tx1.idx[3])) - jx0 + 1;
-    };
+        const int gy0 = min(min(ty0.idx[0], ty0.idx[1]), min(ty0.idx[2], ty0.idx[3]));
+        const int gx0 = min(min(tx0.idx[0], tx0.idx[1]), min(tx0.idx[2], tx0.idx[3]));
+        geo[tid][0] = gy0, geo[tid][1] = gx0;
+        geo[tid][2] = max(max(ty1.idx[0], ty1.idx[1]), max(ty1.idx[2], ty1.idx[3])) - gy0 + 1;  // <= PD
+        geo[tid][3] = max(max(tx1.idx[0], tx1.idx[1]), max(tx1.idx[2], tx1.idx[3])) - gx0 + 1;
+    }
+    __syncthreads();
+    int jy0, jx0, npy, npx;
+    auto geometry = [&](int k) { jy0 = geo[k][0], jx0 = geo[k][1], npy = geo[k][2], npx = geo[k][3]; };
     T pre[PPT];
-    AxisTap<T> tX, tY, tYn;
+    AxisTap<T> tX, tY, tXn, tYn;
     auto fetch = [&](int k) {  // this thread's share of frame k's patch (fixed PD-wide mapping, clamped addresses) and its taps
         const T *src = coef + ((size_t)b * N + k) * h * w;
 #pragma unroll
@@ -987,7 +1001,7 @@ __global__ void __launch_bounds__(256)
             const int idx = tid + 256 * i, py = idx / PD, px = idx - py * PD;
             pre[i] = src[(size_t)min(jy0 + py, h - 1) * w + min(jx0 + px, w - 1)];
         }
-        tX = zx[min(max(qa + cc + fo.ox[k] - SRX_NPAD, 0), W - 1)];
+        tXn = zx[min(max(qa + cc + fo.ox[k] - SRX_NPAD, 0), W - 1)];
         tYn = zy[min(max(pa + rr + fo.oy[k] - SRX_NPAD, 0), H - 1)];
     };
     auto stash = [&]() {
@@ -1005,11 +1019,16 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     SRX_STAMP(2, 1);
     for (int k = 0; k < N; k++) {
-        tY = tYn;
+        tX = tXn, tY = tYn;
+        const int cjy0 = jy0, cjx0 = jx0, cnpy = npy;
+        if (k + 1 < N) {  // next frame's patch and taps: in flight during both passes of this one
+            geometry(k + 1);
+            fetch(k + 1);
+        }
         // row pass: rows[py][cc] = sum_j zx[x(cc)].w[j] * patch[py][idx[j]]
         {
-            const T *p0 = patch + tX.idx[0] - jx0, *p1 = patch + tX.idx[1] - jx0, *p2 = patch + tX.idx[2] - jx0,
-                    *p3 = patch + tX.idx[3] - jx0;
+            const T *p0 = patch + tX.idx[0] - cjx0, *p1 = patch + tX.idx[1] - cjx0, *p2 = patch + tX.idx[2] - cjx0,
+                    *p3 = patch + tX.idx[3] - cjx0;
             // all reads of the patch first: rows and patch share the LDS array, so hipcc would otherwise order each
             // row's store before the next row's loads (one LDS round trip per row)
             T v[(PD + 1) / 2];
@@ -1023,18 +1042,13 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int t = 0; t < (PD + 1) / 2; t++) {
                 const int py = half + 2 * t;
-                if (py < npy && ccok)
+                if (py < cnpy && ccok)
                     rows[py * RS + cc] = v[t];
             }
         }
-        const int cjy0 = jy0;
         __syncthreads();
         if (k == 0)
             SRX_STAMP(2, 2);
-        if (k + 1 < N) {  // next frame's patch and taps: in flight during the column pass
-            geometry(k + 1);
-            fetch(k + 1);
-        }
         // column pass, accumulated over frames: up_k(y(rr), x) = sum_i zy[y].w[i] * rows[idx[i]][x]
         {
             // four columns per LDS read: rows of pitch 4k from a column 4j, so every quad is 16-byte aligned.  ds_read_b128 moves 256 B
@@ -1072,6 +1086,22 @@ __global__ void __launch_bounds__(256)
             SRX_STAMP(2, 4);
     }
     SRX_STAMP(2, 5);
+    if constexpr (ACC) {
+        // through LDS: a lane is a region ROW here, and rows of the plane are what a wave should store (as 48 stores of one word per lane,
+        // 64 rows apart, the accumulate pass took 0.91 ms on C2 where the whole one-pass kernel takes 1.08)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (rrok && cb + t < ncw)
+                reg[rr * LD + cb + t] = acc[t];
+        __syncthreads();
+        T *dst = out + ((size_t)b * (Hp + 3) + pa) * (Wp + 3) + qa;
+        for (int idx = tid; idx < SR * SR; idx += 256) {
+            const int r = idx / SR, c = idx - r * SR;
+            if (r < nrw && c < ncw)
+                dst[(size_t)r * (Wp + 3) + c] = reg[r * LD + c];
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++)
         if (rrok && cb + t < ncw)
@@ -1087,6 +1117,35 @@ __global__ void __launch_bounds__(256)
             out[((size_t)b * H + r) * W + c] = reg[(r + SRX_NPAD - pa) * LD + (c + SRX_NPAD - qa)] / inv_n_div;
     }
     SRX_STAMP(2, 7);
+}
+
+// Second pass of the two-pass form: the fractional shift (FIR + prefilter walks, crop, / N) of one TS x TS output tile from its region
+// of the accumulated W plane [B][H + 27][W + 27] -- k_saa_tile's tail with the region loaded instead of accumulated.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_saa_shift(const T *__restrict__ Wpl, MosaicArgs<T> ma, int H, int W, T inv_n_div, T *__restrict__ out)
+{
+    constexpr int R = TileCfg<T>::R, TS = TileCfg<T>::T_HR, SR = TS + 2 * R + 3, LD = SR;
+    __shared__ __attribute__((aligned(16))) T reg[SR * SR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
+    int bx, by, b;
+    xcd_block(bx, by, b);
+    const int r0 = by * TS, c0 = bx * TS;
+    const int pa = max(0, r0 + SRX_NPAD - R), pb = min(Hp, r0 + SRX_NPAD + TS + R);
+    const int qa = max(0, c0 + SRX_NPAD - R), qb = min(Wp, c0 + SRX_NPAD + TS + R);
+    const int nr = pb - pa, nc = qb - qa, nrw = nr + 3, ncw = nc + 3;
+    fused::load_region<T, SR, SR>(reg, LD, Wpl + ((size_t)b * (Hp + 3) + pa) * (Wp + 3) + qa, (size_t)(Wp + 3), nrw, ncw, wave, lane);
+    __syncthreads();
+    const int r_lo = r0 + SRX_NPAD - pa, r_hi = min(r_lo + TS, nr);
+    fused::walk_pass_2seg<T, LD, 1, R>(reg, 1, ncw, nrw, pa == 0, ma.wfy, tid, r_lo);
+    fused::walk_pass_4seg<T, 1, 1, R>(reg + r_lo * LD, LD, max(r_hi - r_lo, 0), ncw, qa == 0, ma.wfx, tid, c0 + SRX_NPAD - qa);
+    for (int idx = tid; idx < TS * TS; idx += 256) {
+        const int r = r0 + idx / TS, c = c0 + idx % TS;
+        if (r < H && c < W)
+            out[((size_t)b * H + r) * W + c] = reg[(r + SRX_NPAD - pa) * LD + (c + SRX_NPAD - qa)] / inv_n_div;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1383,7 +1442,8 @@ static inline bool saa_eligible(int N, int h, int w, const double *sh, int f)
 
 static inline size_t saa_ws(int eb, int B, int N, int h, int w, int f)
 {
-    return 2 * align_up((size_t)B * N * h * w * eb) + 2 * align_up((size_t)(h > w ? h : w) * f * sizeof(AxisTap<double>));
+    return 2 * align_up((size_t)B * N * h * w * eb) + 2 * align_up((size_t)(h > w ? h : w) * f * sizeof(AxisTap<double>)) +
+           align_up((size_t)B * ((size_t)h * f + 2 * SRX_NPAD + 3) * ((size_t)w * f + 2 * SRX_NPAD + 3) * eb);  // the W plane of the two-pass form
 }
 
 template <typename T>
@@ -1399,6 +1459,9 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
     Arena ar(ws, wsb);
     T *coef = ar.take<T>((size_t)B * N * h * w), *cscr = ar.take<T>((size_t)B * N * h * w);
     AxisTap<T> *zy = ar.take<AxisTap<T>>(H), *zx = ar.take<AxisTap<T>>(W);
+    const bool two_pass = !(call_flags() & SRX_FLAG_DIAG_SAA_ONE_PASS);
+    const int Hw = H + 2 * SRX_NPAD + 3, Ww = W + 2 * SRX_NPAD + 3;
+    T *Wpl = two_pass ? ar.take<T>((size_t)B * Hw * Ww) : nullptr;
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     if (h <= 64 && w <= 64) {
@@ -1428,6 +1491,19 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         ma.wfx[i] = ma.wbx[i] = (T)wv[i];
     constexpr int TS = TileCfg<T>::T_HR;
     const dim3 grid(cdiv(W, TS), cdiv(H, TS), B);
+    if (two_pass) {
+        // the sum over the frames on halo-free tiles of the W plane, then the fractional shift on regions of it (one more trip of the plane
+        // through memory instead of (TS + 2 R + 3)^2 / TS^2 times the zoom work)
+        const dim3 agrid(cdiv(Ww, SAA_ACC_TS), cdiv(Hw, SAA_ACC_TS), B);
+        if (f == 4)
+            SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 4, true>), agrid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, Wpl);
+        else if (f == 3)
+            SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 3, true>), agrid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, Wpl);
+        else
+            SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 2, true>), agrid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, Wpl);
+        SRX_LAUNCH(KID_SAA_SHIFT, (k_saa_shift<T>), grid, dim3(256), 0, st, Wpl, ma, H, W, (T)N, out);
+        return SRX_OK;
+    }
     if (f == 4)
         SRX_LAUNCH(KID_SAA_TILE, (k_saa_tile<T, 4>), grid, dim3(256), 0, st, coef, N, h, w, zy, zx, fo, ma, H, W, (T)N, out);
     else if (f == 3)

@@ -11,7 +11,7 @@ _API = ("blur", "forward_model", "back_project", "shift_and_add", "ibp", "ndi_zo
         "shift_and_add_batched", "ibp_batched", "decimate", "extract_red", "zero_insert", "mean_frames", "mean_frames_batched",
         "quantize_u8", "u8_to_float", "interleave4", "make_gaussian_psf", "set_precision", "get_precision", "precision_override", "last_path",
         "FLAG_AUTO", "FLAG_COMPOSED", "FLAG_FUSED", "FLAG_PER_FRAME", "FLAG_TILES", "FLAG_DIAG_NO_ZERO_FUSE",
-        "FLAG_DIAG_NO_SEPARABLE", "FLAG_DIAG_NO_PREFILTER_TILE", "FLAG_DIAG_V1", "FLAG_DIAG_WIDE_WINDOWS", "FLAG_DIAG_COLUMN_TILES", "FLAG_DIAG_TWO_LAUNCH")
+        "FLAG_DIAG_NO_SEPARABLE", "FLAG_DIAG_NO_PREFILTER_TILE", "FLAG_DIAG_V1", "FLAG_DIAG_WIDE_WINDOWS", "FLAG_DIAG_COLUMN_TILES", "FLAG_DIAG_TWO_LAUNCH", "FLAG_DIAG_SAA_ONE_PASS")
 
 __all__ = list(_API)
 

@@ -15,7 +15,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME, FLAG_TILES = 0, 1, 2, 4, 8
 # diagnostic path switches (include/srx.h): implementations the tests hold to the same results
 FLAG_DIAG_NO_ZERO_FUSE, FLAG_DIAG_NO_SEPARABLE, FLAG_DIAG_NO_PREFILTER_TILE, FLAG_DIAG_V1 = 0x100, 0x200, 0x400, 0x800
-FLAG_DIAG_WIDE_WINDOWS, FLAG_DIAG_COLUMN_TILES, FLAG_DIAG_TWO_LAUNCH = 0x1000, 0x2000, 0x4000
+FLAG_DIAG_WIDE_WINDOWS, FLAG_DIAG_COLUMN_TILES, FLAG_DIAG_TWO_LAUNCH, FLAG_DIAG_SAA_ONE_PASS = 0x1000, 0x2000, 0x4000, 0x8000
 
 _c = ctypes
 _P, _I, _D, _Z, _U = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint

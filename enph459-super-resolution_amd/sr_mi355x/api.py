@@ -30,7 +30,7 @@ import torch
 from . import _lib
 from ._lib import (FLAG_AUTO, FLAG_COMPOSED, FLAG_FUSED, FLAG_PER_FRAME, FLAG_TILES, FLAG_DIAG_NO_ZERO_FUSE,  # noqa: F401  (re-exported)
                    FLAG_DIAG_NO_SEPARABLE, FLAG_DIAG_NO_PREFILTER_TILE, FLAG_DIAG_V1, FLAG_DIAG_WIDE_WINDOWS, FLAG_DIAG_COLUMN_TILES,
-                   FLAG_DIAG_TWO_LAUNCH)
+                   FLAG_DIAG_TWO_LAUNCH, FLAG_DIAG_SAA_ONE_PASS)
 
 _TORCH_DT = {"f32": torch.float32, "f64": torch.float64}
 _ELEM = {"f32": 4, "f64": 8}

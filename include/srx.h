@@ -67,6 +67,8 @@ typedef enum {
 #define SRX_FLAG_DIAG_COLUMN_TILES 0x2000u    /* delta = 0 frames in float32: the transpose-free kernel (float64's default) instead of k_ibp_ztile */
 #define SRX_FLAG_DIAG_TWO_LAUNCH 0x4000u     /* common-fraction frames: the two-launch window kernels (srx_atile.hpp) also where k_ibp_dtile would run */
 #define SRX_FLAG_DIAG_V1 0x800u                /* per-frame fused path with stand-alone prefilter passes (8 launches / iteration) */
+#define SRX_FLAG_DIAG_SAA_ONE_PASS 0x8000u   /* shift_and_add on a common fraction: the one-kernel form (accumulation over the frames with the
+                                              * fractional shift's halo) instead of accumulate + shift (k_saa_tile<ACC> + k_saa_shift); same bits */
 
 int srx_version(void);
 const char *srx_strerror(int status);

@@ -640,6 +640,22 @@ def test_delta_zero_fused_forward_matches_two_kernel_form(prec):
         np.testing.assert_allclose(e_a.cpu().numpy(), e_b.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)
 
 
+def test_shift_and_add_two_pass_equals_one_pass(prec):
+    """Round 4: shift_and_add on a common fraction runs as accumulate (halo-free tiles of the W plane) + shift; the one-kernel form is
+    kept on request.  The same sums in the same order, so the same bits: x2 / x3 / x4, shapes that are not multiples of any tile edge,
+    planes smaller than one tile, a batch."""
+    S.set_precision(prec)
+    rng = np.random.default_rng(77)
+    for f, shifts, (h, w), B in ((4, synth.phase_shifts(4), (64, 64), 3), (2, synth.NOMINAL_5, (150, 233), 1), (3, synth.phase_shifts(3), (41, 57), 2),
+                                 (2, synth.phase_shifts(2), (9, 11), 1), (4, synth.phase_shifts(4)[:7], (100, 30), 1)):
+        lr = torch.from_numpy(rng.uniform(0, 255, (B, len(shifts), h, w))).cuda()
+        a = S.shift_and_add_batched(lr, shifts, f)
+        assert S.last_path() == "mosaic"
+        b = S.shift_and_add_batched(lr, shifts, f, flags=S.FLAG_DIAG_SAA_ONE_PASS)
+        assert S.last_path() == "mosaic"
+        assert torch.equal(a, b), (f, h, w, float((a - b).abs().max()))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # The patch-resident kernel (csrc/srx_patch.hpp): one workgroup per 256 x 256 HR patch, all iterations in one launch
 # ---------------------------------------------------------------------------------------------------------
