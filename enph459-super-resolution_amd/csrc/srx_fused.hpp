@@ -543,7 +543,13 @@ __global__ void __launch_bounds__(256) k_crop_div(const T *__restrict__ vpad, in
 // =========================================================================================
 template <typename T> struct TileCfg;
 template <> struct TileCfg<float> { static constexpr int R = 11, T_HR = 64; };
-template <> struct TileCfg<double> { static constexpr int R = 23, T_HR = 32; };
+// float64 tiles: 64 since round 4 (32 before: with R = 23 a 32-wide tile filters (32 + 52)^2 samples for 32^2 outputs, 6.9x; 64: 3.3x with one
+// block of 100 KB per compute unit instead of two.  rgb_cal_target's shape in float64, us per iteration: k_fwd_tile 75 -> 55, k_bwd_tile
+// 181 -> 128; the x4 frame on the mosaic tile kernels 576 -> 473.  48 fails (k_bwd_mosaic halves its tile))
+#ifndef SRX_TILE64
+#define SRX_TILE64 64
+#endif
+template <> struct TileCfg<double> { static constexpr int R = 23, T_HR = SRX_TILE64; };
 
 // One line of the recursive cubic-spline prefilter on LDS, optionally fused with the 4-tap spline FIR:
 //   MODE 0: line <- P(line)                                      (n = n_in outputs)
