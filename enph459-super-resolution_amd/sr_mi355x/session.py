@@ -432,7 +432,9 @@ def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbo
     """The reference's outer loop (mono_cal_target/run_sr.py:358-360, mono_barcodes/run_sr.py:301) over the sessions this
     rank owns (session i -> rank i mod world, parallel.map_sharded: independent items, no data-path collective), with the PNG
     decode and upload of session k + 1 overlapped with the device work of session k.  -> output directories written: by every
-    rank's sessions, in session order, on rank 0 (one gather of the directory names when the job ends); this rank's own elsewhere.
+    rank's sessions, in session order, on rank 0 (one gather of the directory names when the job ends); [] on the other ranks of a
+    process group (a caller playing one rank of several WITHOUT a group gets its own share's directories).  With a process group,
+    `rank` / `world` must be the group's (ValueError otherwise: ownership and the gather would disagree).
     row_bands: the other way to use several GPUs -- every rank walks ALL sessions and each image is split into row bands."""
     from . import parallel
     if row_bands and kind not in ("mono_cal_target", "rgb_cal_target"):
@@ -466,6 +468,8 @@ def process_sessions(sessions, psf_kernel, output_base, kind, n_iter=None, verbo
         if row_bands or world == 1 or not (dist.is_available() and dist.is_initialized()):
             per_session = [one(i) for i in owned]  # (a caller playing one rank of several without a process group gets its own share)
         else:
+            if dist.get_rank() != rank or dist.get_world_size() != world:
+                raise ValueError(f"rank / world ({rank} / {world}) are not the process group's ({dist.get_rank()} / {dist.get_world_size()})")
             per_session = parallel.map_sharded(one, len(sessions))
     finally:
         feed.close()  # shuts the decode thread down, also when a session raised
