@@ -75,10 +75,11 @@ const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
  * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch), "ztile" (mosaic
  * formulation at integer HR shifts on frames of at least 128x128: one launch per iteration on register-resident tiles),
- * "ctile" (the same in float64, rank-1 PSF), "dtile" (a common fraction > 0 on frames of at least 256x256: one launch per iteration on
+ * "ctile" (the same in float64, rank-1 PSF), "stile" (float64, a common fraction > 0, 256x256 HR patches: two launches per iteration on
+ * register-resident strips that span the patch in the direction their operators run), "dtile" (a common fraction > 0 on frames of at least 256x256: one launch per iteration on
  * overlapping windows), "atile" (the same frames at other sizes: three launches per iteration -- forward windows, the near band, backward windows -- on 128x128 windows), "mosaic" (all shifts share
  * one sub-pixel fraction: dense depth-to-space formulation, tile kernels), "btile"
- * (per-frame fractional shifts at x2, float32, rank-1 PSF: two launches per iteration on register-resident windows), "fused"
+ * (per-frame fractional shifts at x2, float32, any 7x7 PSF: two launches per iteration on register-resident windows), "fused"
  * (per-frame tile kernels), "composed" (primitives, frame by frame). */
 const char *srx_last_path(void);
 
