@@ -261,9 +261,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lane_up(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
 __device__ __forceinline__ float lane_dn(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
 
+// RAD: the PSF's support is (2 RAD + 1)^2 -- 3 for a full 7 x 7; 2 when its outer ring is zero, which is the reference's measured PSF
+// (load_measured_psf crops 5 x 5 around the pinhole peaks, mono_cal_target/run_sr.py:114-152; make_kernel7 embeds it): 25 multiply-adds
+// and four lane shifts per pixel instead of 49 and six (a DPP add costs a wave ~13 cycles, a packed fma ~5: tools/microbench/lane_shift_cost.hip)
+template <int RAD>
 __device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool last, float *Rown, const float *Rprev, const float *Rnext, int s6,
                                              int lane, const float *w56)
 {
+    static_assert(RAD == 2 || RAD == 3, "5 x 5 core or full 7 x 7");
+    constexpr int LO = 3 - RAD, HI = 3 + RAD;  // taps [LO, HI] of either axis
     Rown[s6 + lane] = a[0];
     Rown[s6 + 64 + lane] = a[1];
     Rown[s6 + 128 + lane] = a[2];
@@ -302,23 +308,26 @@ __device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool la
         for (int j = 0; j < NB; j += 2) {
             f2 t[7];
 #pragma unroll
-            for (int u = 0; u < 7; u++) {
-                t[u] = (f2){kw[u][0], kw[u][0]} * pw[j];
+            for (int u = LO; u <= HI; u++) {
+                t[u] = (f2){kw[u][LO], kw[u][LO]} * pw[j + LO];
 #pragma unroll
-                for (int v = 1; v < 7; v++)
+                for (int v = LO + 1; v <= HI; v++)
                     t[u] = __builtin_elementwise_fma((f2){kw[u][v], kw[u][v]}, pw[j + v], t[u]);
             }
             // (scalar adds: each folds its shift into one v_add_f32_dpp; as packed adds the shifts stay separate moves)
             float ox, oy;
-            {
+            if (RAD == 3) {
                 float up = t[1].x + lane_up(t[0].x), dn = t[5].x + lane_dn(t[6].x);
                 up = t[2].x + lane_up(up), dn = t[4].x + lane_dn(dn);
                 ox = (t[3].x + lane_up(up)) + lane_dn(dn);
-            }
-            {
-                float up = t[1].y + lane_up(t[0].y), dn = t[5].y + lane_dn(t[6].y);
-                up = t[2].y + lane_up(up), dn = t[4].y + lane_dn(dn);
-                oy = (t[3].y + lane_up(up)) + lane_dn(dn);
+                float up2 = t[1].y + lane_up(t[0].y), dn2 = t[5].y + lane_dn(t[6].y);
+                up2 = t[2].y + lane_up(up2), dn2 = t[4].y + lane_dn(dn2);
+                oy = (t[3].y + lane_up(up2)) + lane_dn(dn2);
+            } else {
+                const float up = t[2].x + lane_up(t[1].x), dn = t[4].x + lane_dn(t[5].x);
+                ox = (t[3].x + lane_up(up)) + lane_dn(dn);
+                const float up2 = t[2].y + lane_up(t[1].y), dn2 = t[4].y + lane_dn(t[5].y);
+                oy = (t[3].y + lane_up(up2)) + lane_dn(dn2);
             }
             const f2 o = {ox, oy};
             a[j0 + j] = o.x, a[j0 + j + 1] = o.y;
@@ -337,11 +346,13 @@ __device__ __forceinline__ void blur2d_block(float (&a)[64], bool first, bool la
 // own (or outside the image) goes to the plane's trash row / out of the buffer's range.  epart: this iteration's per-tile MSE
 // partial sums (or null); eprev: the previous iteration's, which one interior tile adds up into err_prev[item * err_stride].
 // =========================================================================================================================
-template <bool SEP>
+template <int PSF>  // 0: rank-1 PSF (7 + 7 taps), 3: full 7 x 7, 2: 7 x 7 whose outer ring is zero (5 x 5)
 __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     k_ibp_ztile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, ZTabs tb, ZArgs za, double *__restrict__ epart,
                 const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
 {
+    constexpr bool SEP = PSF == 0;
+    constexpr int RAD = PSF == 2 ? 2 : 3;
     __shared__ float lds[LDS_WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave >> 2, u = wave & 3;
@@ -428,7 +439,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     if (SEP)
         patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, sload8(awx));
     else
-        blur2d_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, tb.k2);
+        blur2d_block<RAD>(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT0, lane, tb.k2);
     SRX_PSTAMP(5);
     float sq = 0.f;
     // ---- near band (tiles on the top / left image edge): strips of b, the listed sums, strips of G
@@ -568,7 +579,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     if (SEP)
         patch::blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, sload8(awx + 8));
     else
-        blur2d_block(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, tb.k2 + 56);
+        blur2d_block<RAD>(r, u == 0, u == 3, Rown, Rlf, Rrt, patch::SLOT1, lane, tb.k2 + 56);
     if (epart && tid == 0) {
         double t = 0.0;
 #pragma unroll
@@ -649,6 +660,7 @@ struct State {
     double scale;
     int B, ntiles, it;
     bool sep;
+    int psf;  // k_ibp_ztile's PSF form: 0 rank 1, 2 the 5 x 5 core of a 7 x 7, 3 full 7 x 7
     float *cur() const { return (it & 1) ? s1 : s0; }
 };
 
@@ -696,6 +708,11 @@ static int setup(State &zs, const float *hr_init, int B, int N, const mosaic::Ax
     hipLaunchKernelGGL(patch::k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
     const bool sep = kc.separable && kt.separable;
+    bool ring0 = true;  // the outer ring of the 7 x 7 weights is zero (the reference's measured PSF is 5 x 5)
+    for (int i = 0; i < 7; i++)
+        for (int e : {i, 42 + i, 7 * i, 7 * i + 6})
+            ring0 = ring0 && kc.k[e] == 0.f && kt.k[e] == 0.f;
+    zs.psf = sep ? 0 : (ring0 ? 2 : 3);
     if (!sep) {
         K2Tab kv;
         for (int u = 0; u < 7; u++)
@@ -737,11 +754,14 @@ static int run(State &zs, int n, double *errors, hipStream_t st)
         float *dst = (zs.it & 1) ? zs.s0 : zs.s1;
         double *ep = errors ? ((j & 1) ? zs.ep1 : zs.ep0) : nullptr;
         const double *eprev = errors && j > 0 ? ((j & 1) ? zs.ep0 : zs.ep1) : nullptr;  // the partial sums iteration j - 1 left
-        if (zs.sep)
-            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<true>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
+        if (zs.psf == 0)
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<0>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
+                       errors ? errors + j - 1 : nullptr, n);
+        else if (zs.psf == 2)
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<2>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
                        errors ? errors + j - 1 : nullptr, n);
         else
-            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<false>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
+            SRX_LAUNCH(KID_IBP_ZTILE, k_ibp_ztile<3>, grid, dim3(256 * NSY), 0, st, src, dst, zs.tb, za, ep, eprev, zs.Vtot, zs.scale,
                        errors ? errors + j - 1 : nullptr, n);
     }
     if (errors && n > 0) {

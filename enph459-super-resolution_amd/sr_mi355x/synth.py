@@ -26,6 +26,13 @@ def phase_shifts(f):
     return [((a - c) / f, (b - c) / f) for a in range(f) for b in range(f)]
 
 
+def full_support_psf():
+    """asymmetric_psf with weight on its outer ring too (the asymmetric one is clipped to its 5 x 5 core, as the reference's measured PSF
+    is): what exercises the full 7 x 7 form of the register-resident kernels."""
+    k = asymmetric_psf() + 0.004 * (1.0 + 0.5 * np.cos(np.arange(49.0)).reshape(7, 7))
+    return k / k.sum()
+
+
 def _gauss_smooth(u, sigma):
     """Separable Gaussian smoothing with edge replication (plain numpy)."""
     r = int(4 * sigma + 0.5)

@@ -313,7 +313,8 @@ FUSED_CFGS = {
     "f4_nom4": (4, synth.NOMINAL_4, "asym", (70, 90), "mosaic"),
     "f4_ph16": (4, synth.phase_shifts(4), "gauss", (70, 90), "mosaic"),     # the bench workload: all fractions 0.5
     "f3_ph9": (3, synth.phase_shifts(3), "asym", (50, 66), "mosaic", "ztile"),  # fractions 0 (3 phases centred on 0); a PSF that is not rank 1: the 7 x 7 form of the one-launch kernel
-    "f2_nom5_asym": (2, synth.NOMINAL_5, "asym", (131, 200), "mosaic", "ztile"),  # the reference's --psf measured on its nominal shifts
+    "f2_nom5_asym": (2, synth.NOMINAL_5, "asym", (131, 200), "mosaic", "ztile"),  # the reference's --psf measured on its nominal shifts (5 x 5 core of a 7 x 7)
+    "f2_nom5_full7": (2, synth.NOMINAL_5, "full7", (131, 200), "mosaic", "ztile"),  # a PSF with weight on its outer ring: the full 7 x 7 form
     "f2_mixed": (2, [(0.5, 0.25), (-0.5, -0.25), (0.0, 0.75)], "asym", (90, 120), "mosaic"),  # y integer, x fraction 0.5
     "f2_multi": (2, [(0.25, 0.25), (1.25, 0.25), (0.25, -0.75), (-0.75, 1.25)], "gauss", (90, 120), "mosaic"),  # C = 4 on one phase
     "f4_frac": (4, [(0.05, 0.3), (0.3, 0.05), (-0.2, -0.45), (0.55, -0.2), (-0.45, 0.55)], "asym", (40, 50), "mosaic"),  # fractions 0.2
@@ -330,7 +331,7 @@ def test_fused_path_vs_oracle(prec, cfg):
         f, shifts, psf_name, (h, w), want = FUSED_CFGS[cfg][:5]
         want_ibp = FUSED_CFGS[cfg][5] if len(FUSED_CFGS[cfg]) > 5 else want
         psf = {"asym": synth.asymmetric_psf(), "gauss": synth.gaussian_psf(),
-               "asym5": synth.asymmetric_psf()[1:6, 1:6] / synth.asymmetric_psf()[1:6, 1:6].sum()}[psf_name]
+               "asym5": synth.asymmetric_psf()[1:6, 1:6] / synth.asymmetric_psf()[1:6, 1:6].sum(), "full7": synth.full_support_psf()}[psf_name]
         truth = synth.truth_image(h * f, w * f, seed=77)
         lr = synth.sensor_frames(np.stack([O.forward_model(truth, psf, s, f) for s in shifts]), seed=78)
         saa_o = O.shift_and_add(list(lr), shifts, f)

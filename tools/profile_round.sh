@@ -41,7 +41,7 @@ cd "$R"
 for wlp in $WLS; do
     wl=${wlp%@*}; prec=f32; [ "$wlp" != "$wl" ] && prec=${wlp#*@}
     tag=$wl; [ "$prec" != f32 ] && tag=${wl}_$prec
-    if [ "$wl" = c2 ]; then
+    if [ "$tag" = c2 ]; then
         timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > "$O/c2_bench.json" 2> "$O/c2_bench.err"
     else
         timeout -k 10 200 python3 bench.py --workload $wl --precision $prec --steps 3 --warmup 1 --no-cpu-baseline > "$O/${tag}_bench.json" 2> "$O/${tag}_bench.err"
