@@ -38,6 +38,7 @@ def source_sha16():
 
 
 PERSISTENT = ("k_ibp_patch",)  # one call = all iterations
+CHUNKED = ("k_ibp_sv", "k_ibp_sh")  # several launches per iteration
 
 
 def per_kernel(path, counter):
@@ -47,22 +48,25 @@ def per_kernel(path, counter):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
             acc[name].append(float(r["Counter_Value"]))
     # a PERSISTENT kernel is launched as a pair per call (two instantiations, every patch iterated by exactly one): per call = pair
-    return {k: sum(v) / (len(v) / 2 if k in PERSISTENT and len(v) % 2 == 0 else len(v)) for k, v in acc.items()}
+    mean = {k: sum(v) / (len(v) / 2 if k in PERSISTENT and len(v) % 2 == 0 else len(v)) for k, v in acc.items()}
+    return mean, {k: sum(v) for k, v in acc.items()}
 
 
 
 
 def main():
     iters = int(sys.argv[4])
-    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    (fetch, fsum), (write, wsum) = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"iters": iters, "profile_tag": sys.argv[6] if len(sys.argv) > 6 else None, "source_sha16": source_sha16(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         nb = int((2 * f + w) * 1024)
-        out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": nb,
-                             "hbm_bytes_per_iteration": nb // iters if k in PERSISTENT else nb}
+        # the float64 strip kernels run the batch in chunks, several launches per iteration (and an empty twin of every horizontal one): all
+        # launches of the profiled step, divided by its iterations
+        per_it = int((2 * fsum.get(k, 0.0) + wsum.get(k, 0.0)) * 1024) // iters if k in CHUNKED else (nb // iters if k in PERSISTENT else nb)
+        out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": nb, "hbm_bytes_per_iteration": per_it}
     dst = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
     try:
         doc = json.load(open(dst))
