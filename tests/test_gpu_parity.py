@@ -769,6 +769,30 @@ def test_strip_kernels_f64_vs_oracle(cfg):
         S.set_precision("f32")
 
 
+def test_strip_kernels_f64_chunks_and_traceless_calls():
+    """The float64 strip path runs a batch in chunks of 128 patches: 130 patches (a full chunk and a short one) against single-item calls of
+    items of both chunks, bit for bit (state and MSE trace); want_errors=False gives the same state; zero iterations copy the input."""
+    S.set_precision("f64")
+    try:
+        f, shifts = 4, synth.phase_shifts(4)
+        psf = synth.gaussian_psf()
+        rng = np.random.default_rng(991)
+        lr = torch.from_numpy(np.rint(rng.uniform(0, 255, (130, 16, 64, 64)))).cuda()
+        lr[7] = lr[7] * 0.5 + 0.25  # one patch with non-integer samples: the float64 mosaic among byte mosaics, in the first chunk
+        init = S.shift_and_add_batched(lr, shifts, f)
+        hr, errs = S.ibp_batched(lr, shifts, psf, init, f, 3, 0.5)
+        assert S.last_path() == "stile"
+        for i in (0, 7, 127, 128, 129):
+            one, e1 = S.ibp_batched(lr[i:i + 1], shifts, psf, init[i:i + 1], f, 3, 0.5)
+            assert torch.equal(one[0], hr[i]) and torch.equal(e1[0], errs[i]), i
+        hr_n, none = S.ibp_batched(lr, shifts, psf, init, f, 3, 0.5, want_errors=False)
+        assert none is None and torch.equal(hr_n, hr)
+        hr_0, _ = S.ibp_batched(lr[:2], shifts, psf, init[:2], f, 0, 0.5)
+        assert torch.equal(hr_0, init[:2])
+    finally:
+        S.set_precision("f32")
+
+
 def test_patch_tables_from_the_lr_frames_equal_the_plane_route():
     """Round 4: on a full phase grid the patch path builds its operand planes straight from the LR frames (k_patch_flags, k_patch_build,
     k_patch_near_build) instead of through the batch's M / C / Mu planes (k_mosaic_build, k_patch_prep, k_patch_near_m: kept, on request,
