@@ -18,7 +18,7 @@ from oracle import sr_oracle as O  # noqa: E402
 
 def random_case(rng):
     f = int(rng.choice([2, 2, 3, 4, 4]))
-    kind = rng.choice(["phase", "lattice", "free", "far", "patch", "frame0", "shifted"], p=[0.22, 0.22, 0.16, 0.1, 0.1, 0.1, 0.1])
+    kind = rng.choice(["phase", "lattice", "free", "far", "patch", "frame0", "shifted", "window"], p=[0.2, 0.2, 0.14, 0.1, 0.1, 0.1, 0.1, 0.06])
     N = int(rng.integers(1, 7))
     if kind == "patch":      # k_ibp_patch's domain: a 256 x 256 HR patch, Gaussian PSF, a subset of a phase grid with delta = 1/2
         f = int(rng.choice([2, 4]))
@@ -26,6 +26,13 @@ def random_case(rng):
         N = int(rng.integers(2, len(grid) + 1))
         idx = rng.choice(len(grid), size=N, replace=False)
         return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], 256 // f, 256 // f, synth.gaussian_psf(), int(rng.integers(1, 6)), kind
+    if kind == "window":     # k_ibp_dtile's domain: a common fraction > 0 on a frame of at least 256 rows x 192 columns (HR), rows in quads, columns
+        f = int(rng.choice([2, 4]))  # in groups of 16; a subset of a phase grid (byte mosaic + 0/1 masks) or, one time in three, non-integer frames
+        grid = synth.phase_shifts(f)
+        N = int(rng.integers(2, len(grid) + 1))
+        idx = rng.choice(len(grid), size=N, replace=False)
+        H, W = 4 * int(rng.integers(64, 100)), 16 * int(rng.integers(12, 26))
+        return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], -(-H // f), -(-W // f), synth.gaussian_psf(), int(rng.integers(1, 4)), kind
     if kind == "shifted":    # k_ibp_bfwd / k_ibp_bbwd's domain: x2, per-frame fractions, |2 s| <= 4, Gaussian PSF, frames of one to several windows
         N = int(rng.integers(2, 9))
         shifts = [(float(rng.uniform(-1.99, 1.99)), float(rng.uniform(-1.99, 1.99))) for _ in range(N)]
