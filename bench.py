@@ -86,6 +86,10 @@ def workload(synth, name, batch, iters):
         return (4, (64, 64), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1024, iters or 80,
                 "C2: x4 multi-frame SR of 64x64 LR patches -> 256x256 HR, N=16 frames (all 4x4 sub-pixel phases), "
                 "7x7 Gaussian PSF, shift_and_add + ibp(80 it, step 0.5)")
+    if name == "c2_measured":  # the same patches with a PSF that is not rank 1 (a 5 x 5 core like the reference's load_measured_psf output)
+        return (4, (64, 64), synth.phase_shifts(4), synth.asymmetric_psf(), batch or 1024, iters or 80,
+                "C2, --psf measured: x4 multi-frame SR of 64x64 LR patches -> 256x256 HR, N=16 frames (all 4x4 sub-pixel phases), "
+                "asymmetric (non-separable) 7x7 PSF, shift_and_add + ibp(80 it, step 0.5)")
     if name == "c3_mono":  # mono_cal_target/run_sr.py:50-66: 5 frames, nominal +-0.5 px, f=2, 80 iterations
         return (2, (1536, 2048), synth.NOMINAL_5, synth.gaussian_psf(), batch or 1, iters or 80,
                 "C3-mono: the reference's mono_cal_target shape, 1536x2048 LR -> 3072x4096, N=5 nominal shifts, Gaussian PSF")
@@ -304,7 +308,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: 1024 patches for c2, 1 frame for c3_*)")
     ap.add_argument("--iters", type=int, default=0, help="IBP iterations (default: the reference's 80; 50 for c3_rgb)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_rgb_measured", "c3_f4", "c3_f4_float"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_measured", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_rgb_measured", "c3_f4", "c3_f4_float"],
                     help="c2 (default, the headline): 1024 x4 patches, N=16 phases; c3_mono / c3_rgb: the reference's own "
                          "full-frame shapes (mono_cal_target N=5 nominal f=2 3072x4096; rgb_cal_target N=4 measured f=2 1536x2048); "
                          "c3_f4: the x4 variant of SURVEY 8d, 768x1024 -> 3072x4096, all 16 phases")
@@ -378,7 +382,7 @@ def main():
     legs = None
     if rank == 0 and world == 1 and not args.no_roofline and not args.no_secondary and args.workload == "c2":
         legs = {}
-        for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c3_mono", "c3_mono", "f32", None), ("c3_mono_f64", "c3_mono", "f64", None),
+        for tag, wname, lprec, lb in (("f64", "c2", "f64", None), ("c2_measured", "c2_measured", "f32", None), ("c3_mono", "c3_mono", "f32", None), ("c3_mono_f64", "c3_mono", "f64", None),
                                       ("c3_rgb", "c3_rgb", "f32", None),
                                       ("c3_f4", "c3_f4", "f32", None), ("c3_mono_x8", "c3_mono", "f32", 8),
                                       ("c3_mono_measured", "c3_mono_measured", "f32", None), ("c3_rgb_x8", "c3_rgb", "f32", 8),

@@ -31,7 +31,7 @@ namespace mosaic {
 struct AxisPlan;
 }
 namespace patch {  // srx_patch.hpp: the patch-resident iteration (one workgroup per 256 x 256 HR patch)
-static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f);
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f, bool rank1_only = false);
 static inline size_t tabs_bytes(int B, int N);
 }  // namespace patch
 namespace ztile {  // srx_ztile.hpp: delta = 0 on CU-resident 256 x 256 tiles of a large frame, one launch per iteration

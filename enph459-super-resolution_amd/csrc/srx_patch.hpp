@@ -120,9 +120,12 @@ struct PatchTabs {
     const uint2 *nrec;          // [NN_PAD]  x = cnt | cu << 8 | dst << 16, y = strip offset of the pixel's own Y sample
     const uint2 *nent;          // [ngrp][NN_PAD] four 16-bit strip offsets per group
     const float2 *Mn;           // [B][NN_PAD] (M, Mu) of the near-band pixels
+    const float *k2;            // [2][7][8]: a PSF that is not rank 1 -- weights of the forward blur (times kq^2) and of the adjoint blur in COLUMN layout:
+                                // k2[t][c][r] = K[r][c], lane-direction tap c, register-direction tap r (rows padded to 8 words)
 };
 
 // ---- eligibility ----------------------------------------------------------------------------------------------------
+static inline bool c01_masks(const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, int N, int f, unsigned long long ry[4], unsigned long long rx[4]);
 static inline bool axis_ok(const mosaic::AxisPlan &pl, int N, int f)
 {
     int nmin = pl.n[0], nmax = pl.n[0];
@@ -133,7 +136,7 @@ static inline bool axis_ok(const mosaic::AxisPlan &pl, int N, int f)
     return !pl.zero && nmax >= 0 && nmax <= 1 && nmin <= 0 && nmax - nmin <= 3 && nmax - nmin <= f - 1 && -nmin < f;
 }
 
-static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f)
+static inline bool eligible(int elem_bytes, int N, int H, int W, const double *sh, const double *k, int kh, int kw, int f, bool rank1_only)
 {
     if (elem_bytes != 4 || H != PN || W != PN || f < 2)
         return false;
@@ -142,8 +145,16 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
         return false;
     fused::Kernel7<float> kc;
     fused::make_kernel7<float>(k, kh, kw, false, kc);
-    if (!(kc.separable && axis_ok(py, N, f) && axis_ok(px, N, f)))
+    // (round 4: a PSF that is not rank 1 runs the 7 x 7 form of the two blurs, blur2d_pass1 / blur2d_fix -- on full phase grids, i.e. count maps
+    // that are 0/1 products; with a count PLANE (frames sharing a phase, lattices) the 7 x 7 instantiations gave results that changed from call to
+    // call on two of four configurations (tools/dev/pt_check.py; not understood: the tile kernels keep those))
+    if (!((kc.separable || !rank1_only) && axis_ok(py, N, f) && axis_ok(px, N, f)))
         return false;
+    if (!kc.separable) {
+        unsigned long long ry[4], rx[4];
+        if (!c01_masks(py, px, N, f, ry, rx))
+            return false;
+    }
     // the near band within the kernel's two-pixels-per-thread descriptor lists (iterate() computes the same count)
     auto span = [&](const mosaic::AxisPlan &pl, int &ex, int &nb) {
         int nmin = pl.n[0], nmax = pl.n[0];
@@ -604,10 +615,12 @@ __device__ __forceinline__ void fwd_chain(float (&a)[64], bool first, bool last,
 // ---- backward chain of one block ------------------------------------------------------------------------------------
 // a[] in: G samples of this block; gm1 / gp1 / gp2: G just before / after the block (halo exchange done by the caller);
 // gtop: G[-ex] of the line (first block).  out: corr = blur'( crop P( FIR_b G ) ).  Two workgroup barriers.
-template <typename F, typename P>
-__device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool first, bool last, float *Rown, const float *Rprev,
-                                          const float *Rnext, int s1, int s6, int lane, const f8 wfb, const f8 kt, float gm1, float gp1,
-                                          float gp2, float gtop, F mid, P post)
+// BLUR = false (a PSF that is not rank 1: the adjoint blur is blur2d's, once, in column layout): out = the coefficients themselves, and
+// hlo / hhi = the three coefficients before / after the block (zero outside the image) for that blur.
+template <bool BLUR, typename F, typename P>
+__device__ __forceinline__ void bwd_chain_x(float (&a)[64], float (&out)[64], bool first, bool last, float *Rown, const float *Rprev,
+                                            const float *Rnext, int s1, int s6, int lane, const f8 wfb, const f8 kt, float gm1, float gp1,
+                                            float gp2, float gtop, F mid, P post, float (&hlo)[3], float (&hhi)[3])
 {
     const float z = PZ;
     const float w0 = wfb[4], w1 = wfb[5], w2 = wfb[6], w3 = wfb[7];
@@ -667,6 +680,13 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
     for (int i = 0; i < 64; i++)
         e[3 + i] = a[i];
     SRX_PSTAMP(20);
+    if (!BLUR) {
+        hlo[0] = e[0], hlo[1] = e[1], hlo[2] = e[2], hhi[0] = e[67], hhi[1] = e[68], hhi[2] = e[69];
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            out[i] = e[3 + i];
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         mid(q);  // caller's hook before every quarter of the blur (loads / stores to overlap with it)
@@ -680,6 +700,15 @@ __device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <typename F, typename P>
+__device__ __forceinline__ void bwd_chain(float (&a)[64], float (&out)[64], bool first, bool last, float *Rown, const float *Rprev,
+                                          const float *Rnext, int s1, int s6, int lane, const f8 wfb, const f8 kt, float gm1, float gp1,
+                                          float gp2, float gtop, F mid, P post)
+{
+    float hlo[3], hhi[3];
+    bwd_chain_x<true>(a, out, first, last, Rown, Rprev, Rnext, s1, s6, lane, wfb, kt, gm1, gp1, gp2, gtop, mid, post, hlo, hhi);
 }
 
 // blur (7-tap correlation) of a block with three samples from either neighbour block: halo exchange through the waves' own LDS
@@ -726,6 +755,115 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
     }
 }
 
+// ---- 7 x 7 correlation with a PSF that is not rank 1, on one block of the 4 x 4 grid, COLUMN layout (round 4) --------------------------
+// out[i][l] = sum_{r, c} K[r][c] in[i - 3 + r][l - 3 + c]: the r direction runs along the registers (three rows from the blocks above / below:
+// hl / hr), the c direction along the LANES -- every lane forms the seven column sums t_c = sum_r K[r][c] in[i - 3 + r] of its own column and
+// a Horner scheme of one-lane wave shifts combines them, out = t_3 + up(t_2 + up(t_1 + up(t_0))) + dn(t_4 + dn(t_5 + dn(t_6))) (k_ibp_ztile's
+// blur2d_block; two adjacent rows advance as one packed pair).  What k_ibp_ztile does not have is a neighbour in the lane direction: here the
+// waves left / right hold the next columns.  The shifts run with zero shifted in (pass 1), and by linearity what is missing at a wave's first /
+// last three lanes are the neighbour's OWN Horner partials at its last / first lane -- U1 = t_0, U2 = t_1 + up(U1), U3 = t_2 + up(U2) at lane 63,
+// D1 = t_6, D2, D3 at lane 0, none of which depends on a fill: lanes 63 and 0 publish them (one 16-byte LDS store per row with the other
+// lanes masked off; exec is set and restored inside the asm so that the loop stays one basic block), and behind a barrier every lane adds
+// the one it lacks (lane 0 <- U3, 1 <- U2, 2 <- U1 of the left wave; 63 <- D3, 62 <- D2, 61 <- D1 of the right one; a zero word elsewhere):
+// one LDS read and one add per row (pass 2, blur2d_fix, which also carries the caller's epilogue: the IBP update must see the complete sum).
+// RAD = 2: the PSF's outer ring is zero (the reference's measured PSF): 25 multiply-adds and four shifts per pixel instead of 49 and six.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float lane_up(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float lane_dn(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
+constexpr int SLOT_E = 1536;  // a wave's published partials: [64 rows][8 words] = U1 U2 U3 . D1 D2 D3 . (inside its private region, behind the exchange slots)
+constexpr int SLOT_D = 512;   // 256 words between the exchange slots: where the lanes that publish nothing store (distinct quads: no bank conflict)
+constexpr int SLOT_Z = 2048;  // eight zero words (what the lanes that lack nothing add; what a wave at the patch's edge reads for its missing neighbour)
+static_assert(SLOT_D >= SLOT0 + 448 && SLOT_D + 256 <= SLOT1 && SLOT_E >= SLOT1 + 448 && SLOT_E + 512 <= SLOT_Z && SLOT_Z + 8 <= RW, "slots inside the wave's region");
+
+#ifndef SRX_PATCH_B2D_NB
+#define SRX_PATCH_B2D_NB 4
+#endif
+template <int RAD>
+__device__ __forceinline__ void blur2d_pass1(float (&a)[64], const float (&hl)[3], const float (&hr)[3], float *Rown, int lane, const float *w56)
+{
+    static_assert(RAD == 2 || RAD == 3, "5 x 5 core or full 7 x 7");
+    constexpr int LO = 3 - RAD, HI = 3 + RAD;
+    f8 kw[7];  // kw[c][r]
+#pragma unroll
+    for (int c = 0; c < 7; c++)
+        kw[c] = sload8(w56 + 8 * c);
+    if (lane < 8)
+        Rown[SLOT_Z + lane] = 0.f;
+    // where this lane's 16 bytes of a row go: lane 63 -> U half, lane 0 -> D half of the row's slot; every other lane into its own quad of a
+    // dump area (the store is unpredicated: the loop stays one basic block)
+    f4 *edst = reinterpret_cast<f4 *>(__builtin_assume_aligned(lane == 63 ? Rown + SLOT_E : lane == 0 ? Rown + SLOT_E + 4 : Rown + SLOT_D + 4 * lane, 16));
+    const int estr = (lane == 63 || lane == 0) ? 2 : 0;  // in units of 16 bytes per row
+    constexpr int NB = SRX_PATCH_B2D_NB;
+    float c0 = hl[0], c1 = hl[1], c2 = hl[2];
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += NB) {
+        float w[NB + 6];
+        w[0] = c0, w[1] = c1, w[2] = c2;
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            w[3 + j] = a[j0 + j];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            w[NB + 3 + j] = j0 + NB + j < 64 ? a[j0 + NB + j] : hr[j];
+        c0 = w[NB], c1 = w[NB + 1], c2 = w[NB + 2];
+        f2 pw[NB + 5];  // (x, x + 1) for every x of the window
+#pragma unroll
+        for (int m = 0; m < NB + 5; m++)
+            pw[m] = (f2){w[m], w[m + 1]};
+#pragma unroll
+        for (int j = 0; j < NB; j += 2) {
+            f2 t[7];
+#pragma unroll
+            for (int c = LO; c <= HI; c++) {
+                t[c] = (f2){kw[c][LO], kw[c][LO]} * pw[j + LO];
+#pragma unroll
+                for (int r = LO + 1; r <= HI; r++)
+                    t[c] = __builtin_elementwise_fma((f2){kw[c][r], kw[c][r]}, pw[j + r], t[c]);
+            }
+            float o[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float u1, u2, u3, d1, d2, d3, res;
+                if (RAD == 3) {
+                    u1 = h ? t[0].y : t[0].x, d1 = h ? t[6].y : t[6].x;
+                    u2 = (h ? t[1].y : t[1].x) + lane_up(u1), d2 = (h ? t[5].y : t[5].x) + lane_dn(d1);
+                    u3 = (h ? t[2].y : t[2].x) + lane_up(u2), d3 = (h ? t[4].y : t[4].x) + lane_dn(d2);
+                    res = ((h ? t[3].y : t[3].x) + lane_up(u3)) + lane_dn(d3);
+                } else {  // the missing first stage: U1 = D1 = 0
+                    u1 = 0.f, d1 = 0.f;
+                    u2 = h ? t[1].y : t[1].x, d2 = h ? t[5].y : t[5].x;
+                    u3 = (h ? t[2].y : t[2].x) + lane_up(u2), d3 = (h ? t[4].y : t[4].x) + lane_dn(d2);
+                    res = ((h ? t[3].y : t[3].x) + lane_up(u3)) + lane_dn(d3);
+                }
+                o[h] = res;
+                const f4 ev = lane == 0 ? (f4){d1, d2, d3, 0.f} : (f4){u1, u2, u3, 0.f};
+                edst[(j0 + j + h) * estr] = ev;
+            }
+            a[j0 + j] = o[0], a[j0 + j + 1] = o[1];
+            asm volatile("" : "+v"(a[j0 + j]), "+v"(a[j0 + j + 1]));  // (as in k_ibp_ztile: the last adds of a pixel stay with its arithmetic)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// pass 2: lfirst / llast: no wave before / after this one in the lane direction; Rlo / Rhi: the regions of those waves.  pre(q) runs before
+// quarter q of the rows (the parked state's loads), post(i, v) is the epilogue of row i.
+template <int RAD, typename PRE, typename POST>
+__device__ __forceinline__ void blur2d_fix(float (&a)[64], bool lfirst, bool llast, float *Rown, const float *Rlo, const float *Rhi, int lane, PRE pre, POST post)
+{
+    // word offset of the partial this lane lacks inside a row's slot of the neighbour: U3, U2, U1 for lanes 0, 1, 2; D1, D2, D3 for 61, 62, 63
+    const float *src = lane < 3 ? (lfirst ? Rown + SLOT_Z : Rlo + SLOT_E + 2 - lane) : lane >= 61 ? (llast ? Rown + SLOT_Z : Rhi + SLOT_E + 4 + lane - 61) : Rown + SLOT_Z;
+    const int str = (lane < 3 ? !lfirst : lane >= 61 ? !llast : false) ? 8 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        pre(q);
+#pragma unroll
+        for (int i = 16 * q; i < 16 * q + 16; i++)
+            a[i] = post(i, a[i] + src[i * str]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // =========================================================================================================================
 // All n_iter IBP iterations of one patch.  grid B, block 1024 (16 waves = 4 x 4 blocks of 64 x 64).
 // Between iterations the HR state stays in registers (column layout); per iteration the kernel stores it (hr_out doubles as
@@ -735,13 +873,21 @@ __device__ __forceinline__ void blur_block(float (&a)[64], bool first, bool last
 struct AxisWPair {
     AxisW y, x;
 };
+struct K2Pair {
+    float v[112];
+};
+__global__ void k_patch_k2(K2Pair t, float *__restrict__ dst)
+{
+    if (threadIdx.x < 112)
+        dst[threadIdx.x] = t.v[threadIdx.x];
+}
 __global__ void k_patch_params(AxisWPair v, AxisW *dst)
 {
     dst[0] = v.y;
     dst[1] = v.x;
 }
 
-template <bool C01, bool M8>
+template <bool C01, bool M8, int PSF = 0>  // PSF: 0 rank 1 (7 + 7 taps per blur), 3 full 7 x 7, 2 a 7 x 7 whose outer ring is zero
 __global__ void __launch_bounds__(1024)
     k_ibp_patch(const float *__restrict__ hr_in, float *__restrict__ hr_out, PatchTabs tb, PatchArgs pa, const double *__restrict__ Vtot,
                 double scale, double *__restrict__ errors, int n_iter)
@@ -823,7 +969,28 @@ __global__ void __launch_bounds__(1024)
                 fused::buf_store<float>(a[i], rs_out, l4 + (i & 3) * PN * 4, cbl + (i >> 2) * PN * 16);
 #endif
         }
-        blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
+        if (PSF == 0) {
+            blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
+        } else {  // both directions of the PSF here (its weights carry kq^2: the H chain of stage B expects a scaled input too)
+            Rown[SLOT0 + lane] = a[0];
+            Rown[SLOT0 + 64 + lane] = a[1];
+            Rown[SLOT0 + 128 + lane] = a[2];
+            Rown[SLOT0 + 192 + lane] = a[61];
+            Rown[SLOT0 + 256 + lane] = a[62];
+            Rown[SLOT0 + 320 + lane] = a[63];
+            __syncthreads();
+            float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+            if (s != 0)
+                hl[0] = Rup[SLOT0 + 192 + lane], hl[1] = Rup[SLOT0 + 256 + lane], hl[2] = Rup[SLOT0 + 320 + lane];
+            if (s != 3)
+                hr[0] = Rdn[SLOT0 + lane], hr[1] = Rdn[SLOT0 + 64 + lane], hr[2] = Rdn[SLOT0 + 128 + lane];
+            blur2d_pass1<PSF == 2 ? 2 : 3>(a, hl, hr, Rown, lane, tb.k2);
+            __syncthreads();
+            blur2d_fix<PSF == 2 ? 2 : 3>(a, u == 0, u == 3, Rown, Rlf, Rrt, lane, [](int) {}, [](int, float v) { return v; });
+#ifdef SRX_PATCH_B2D_SYNC
+            __syncthreads();
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(1);
         fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1, SLOT0, lane, sload8(awy + 16), yex);
@@ -848,7 +1015,8 @@ __global__ void __launch_bounds__(1024)
         const bool rownear = wrapped || gy < nby;
         const float crow = C01 ? (float)((rmask >> lane) & 1ull) : 0.f;
         // ================= stage B: row layout, lane = row 64 s + lane, r[j] = column 64 u + j =================
-        blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
+        if (PSF == 0)
+            blur_block(r, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(5);
@@ -1037,7 +1205,9 @@ __global__ void __launch_bounds__(1024)
             const float gtop = exx ? gexx : r[0];
             const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];
             const float gp1 = u == 3 ? 0.f : Rrt[SLOT1 + lane], gp2 = u == 3 ? 0.f : Rrt[SLOT1 + 64 + lane];
-            bwd_chain(r, a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop, [](int) {}, [](int, float v) { return v; });
+            float hlo[3], hhi[3];  // (unused here: the adjoint 7 x 7 runs once, in stage C)
+            bwd_chain_x<PSF == 0>(r, a, u == 0, u == 3, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop, [](int) {},
+                                  [](int, float v) { return v; }, hlo, hhi);
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(10);
@@ -1064,8 +1234,7 @@ __global__ void __launch_bounds__(1024)
             const float gtop = exy ? rowbuf[64 * u + lane] : r[0];
             const float gm1 = s == 0 ? gtop : Rup[SLOT0 + 128 + lane];
             const float gp1 = s == 3 ? 0.f : Rdn[SLOT0 + lane], gp2 = s == 3 ? 0.f : Rdn[SLOT0 + 64 + lane];
-            bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop,
-                      [&](int q) {
+            auto mid = [&](int q) {
                           // the parked state in 16-row batches, two in flight: batch q is consumed by quarter q of the blur
                           auto load16 = [&](float(&ld)[16], int bq) {
 #if SRX_PARK16
@@ -1092,11 +1261,24 @@ __global__ void __launch_bounds__(1024)
                               load16(hv, 2);
                           else if (q == 2)
                               load16(hw, 3);
-                      },
-                      [&](int i, float corr) {
+                      };
+            auto post = [&](int i, float corr) {
                           // the update, fused into the blur's epilogue: hr <- clip(hr + step * corr / N, 0, 255), one v_med3_f32
                           return __builtin_amdgcn_fmed3f(fmaf(corr, sn, ((i >> 4) & 1) ? hw[i & 15] : hv[i & 15]), 0.f, 255.f);
-                      });
+                      };
+            if (PSF == 0) {
+                bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, mid, post);
+            } else {  // the coefficients, then the adjoint 7 x 7 of both directions; the update is the epilogue of its second pass
+                float hl[3], hr[3];
+                bwd_chain_x<false>(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, [](int) {},
+                                   [](int, float v) { return v; }, hl, hr);
+                blur2d_pass1<PSF == 2 ? 2 : 3>(a, hl, hr, Rown, lane, tb.k2 + 56);
+                __syncthreads();
+                blur2d_fix<PSF == 2 ? 2 : 3>(a, u == 0, u == 3, Rown, Rlf, Rrt, lane, mid, post);
+#ifdef SRX_PATCH_B2D_SYNC
+                __syncthreads();
+#endif
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         SRX_PSTAMP(14);
@@ -1226,7 +1408,7 @@ static inline size_t tabs_bytes(int B, int N)
 {
     const size_t ngrp = ((size_t)N + 3) / 4;
     return align_up(sizeof(BuildMaps)) + align_up((size_t)B * PN * PN * 4) + align_up((size_t)B * (PN / 4) * PN * 4) + align_up((size_t)B * 4) + align_up((size_t)PN * PN * 4) +
-           align_up((size_t)NN_PAD * 8) + align_up(ngrp * NN_PAD * 8) + align_up((size_t)B * NN_PAD * 8) + align_up(2 * sizeof(AxisW));
+           align_up((size_t)NN_PAD * 8) + align_up(ngrp * NN_PAD * 8) + align_up((size_t)B * NN_PAD * 8) + align_up(2 * sizeof(AxisW)) + align_up(112 * 4);
 }
 
 // the iteration loop; the per-call tables (M, C, Mu, near lists, Vtot) are srx_mosaic.hpp's, built by its ibp()
@@ -1244,6 +1426,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     uint2 *nrec = ar.take<uint2>(NN_PAD), *nent = ar.take<uint2>((size_t)ngrp * NN_PAD);
     float2 *Mn = ar.take<float2>((size_t)B * NN_PAD);
     AxisW *aw = ar.take<AxisW>(2);
+    float *k2 = ar.take<float>(112);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     PatchArgs pa;
@@ -1294,15 +1477,45 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     }
     hipLaunchKernelGGL(k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
-    PatchTabs tb{Mt, Mt8, m8, Ct, aw, nrec, nent, Mn};
-    // both mosaic forms over the whole batch: every patch is iterated by exactly one of the two launches (k_patch_prep's m8 flag)
-    if (pa.c01) {
-        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<true, true>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
-        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<true, false>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
-    } else {
-        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<false, true>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
-        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<false, false>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);
+    // a PSF that is not rank 1: the 7 x 7 weights in column layout (lane-direction tap, then register-direction tap), the forward ones
+    // times kq^2; form 2 when the outer ring is zero (the reference's measured PSF: a 5 x 5 core)
+    int psf = 0;
+    if (!(kc.separable && kt.separable)) {
+        const double kq = -6.0 * ZD;
+        bool ring0 = true;
+        for (int i = 0; i < 7; i++)
+            for (int e : {i, 42 + i, 7 * i, 7 * i + 6})
+                ring0 = ring0 && kc.k[e] == 0.f && kt.k[e] == 0.f;
+        psf = ring0 ? 2 : 3;
+        K2Pair kv;
+        for (int c = 0; c < 7; c++)
+            for (int r = 0; r < 8; r++) {
+                kv.v[8 * c + r] = r < 7 ? (float)(kq * kq * (double)kc.k[7 * r + c]) : 0.f;
+                kv.v[56 + 8 * c + r] = r < 7 ? kt.k[7 * r + c] : 0.f;
+            }
+        hipLaunchKernelGGL(k_patch_k2, dim3(1), dim3(128), 0, st, kv, k2);
+        SRX_CHECK_LAUNCH();
     }
+    PatchTabs tb{Mt, Mt8, m8, Ct, aw, nrec, nent, Mn, k2};
+    // both mosaic forms over the whole batch: every patch is iterated by exactly one of the two launches (k_patch_prep's m8 flag)
+#define SRX_PATCH_PAIR(C01_, PSF_)                                                                                                              \
+    do {                                                                                                                                        \
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, true, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);  \
+        SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, false, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter); \
+    } while (0)
+    if (psf != 0 && !pa.c01)
+        return SRX_E_UNSUPPORTED;  // (eligible() keeps these on the tile kernels)
+    if (pa.c01) {
+        if (psf == 0)
+            SRX_PATCH_PAIR(true, 0);
+        else if (psf == 2)
+            SRX_PATCH_PAIR(true, 2);
+        else
+            SRX_PATCH_PAIR(true, 3);
+    } else {
+        SRX_PATCH_PAIR(false, 0);
+    }
+#undef SRX_PATCH_PAIR
     return SRX_OK;
 }
 

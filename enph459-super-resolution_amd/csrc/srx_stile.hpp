@@ -272,7 +272,7 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
 {
     if (elem_bytes != 8 || (call_flags() & SRX_FLAG_TILES))
         return false;
-    return patch::eligible(4, N, H, W, sh, k, kh, kw, f);  // (rank 1 is decided on the float64 weights there too)
+    return patch::eligible(4, N, H, W, sh, k, kh, kw, f, true);  // rank-1 PSFs only (rank 1 is decided on the float64 weights there too)
 }
 
 // ---- once per call: the patch path's operand planes in T ------------------------------------------------------------------------------

@@ -660,9 +660,9 @@ def test_shift_and_add_two_pass_equals_one_pass(prec):
 # ---------------------------------------------------------------------------------------------------------
 # The patch-resident kernel (csrc/srx_patch.hpp): one workgroup per 256 x 256 HR patch, all iterations in one launch
 # ---------------------------------------------------------------------------------------------------------
-def _patch_case(f, shifts, n_items, integer_lr=True, seed=300):
+def _patch_case(f, shifts, n_items, integer_lr=True, seed=300, psf_name="gauss"):
     from oracle import sr_oracle as O
-    psf = synth.gaussian_psf()
+    psf = {"gauss": synth.gaussian_psf(), "asym": synth.asymmetric_psf(), "full7": synth.full_support_psf()}[psf_name]
     O.set_threads(8)
     try:
         truths = [synth.truth_image(256, 256, seed=seed + i) for i in range(n_items)]
@@ -683,16 +683,26 @@ PATCH_CFGS = {
     "x4_dup": (4, synth.phase_shifts(4) + [synth.phase_shifts(4)[5]], True),
     "x2_half_row": (2, [(0.25, 0.25), (0.25, -0.25)], True),
 }
+# round 4: a PSF that is not rank 1 on the patch kernel (the 7 x 7 form of its two blurs; "asym": outer ring zero like the reference's measured PSF)
+PATCH_CFGS_7X7 = {
+    "x4_grid_asym": (4, synth.phase_shifts(4), True, "asym"),
+    "x4_grid_full7": (4, synth.phase_shifts(4), True, "full7"),
+    "x4_grid_float_asym": (4, synth.phase_shifts(4), False, "asym"),
+    "x4_sub12_full7": (4, [s for s in synth.phase_shifts(4) if s[0] > -0.3], False, "full7"),  # a 3 x 4 product grid, non-integer frames
+    "x2_grid_asym": (2, synth.phase_shifts(2), True, "asym"),
+    "x2_half_row_full7": (2, [(0.25, 0.25), (0.25, -0.25)], False, "full7"),
+}
 
 
-@pytest.mark.parametrize("cfg", sorted(PATCH_CFGS))
+@pytest.mark.parametrize("cfg", sorted(PATCH_CFGS) + sorted(PATCH_CFGS_7X7))
 def test_patch_kernel_vs_oracle(cfg):
     """k_ibp_patch against the oracle after 1, 2, 10 and 80 iterations (HR state and MSE trace), and against the tile kernels:
-    full phase grids (uint8 mosaic + 0/1 count masks), non-integer frames (float mosaic), frames sharing a phase (count plane)."""
+    full phase grids (uint8 mosaic + 0/1 count masks), non-integer frames (float mosaic), frames sharing a phase (count plane); round 4:
+    the same with PSFs that are not rank 1 (a 5 x 5 core like the reference's measured PSF, and full 7 x 7 support)."""
     from oracle import sr_oracle as O
     S.set_precision("f32")
-    f, shifts, integer_lr = PATCH_CFGS[cfg]
-    psf, lr, saa = _patch_case(f, shifts, 2, integer_lr)
+    f, shifts, integer_lr = (PATCH_CFGS.get(cfg) or PATCH_CFGS_7X7[cfg])[:3]
+    psf, lr, saa = _patch_case(f, shifts, 2, integer_lr, psf_name=PATCH_CFGS_7X7[cfg][3] if cfg in PATCH_CFGS_7X7 else "gauss")
     O.set_threads(8)
     try:
         for n in (1, 2, 10, 80):
@@ -708,6 +718,9 @@ def test_patch_kernel_vs_oracle(cfg):
     assert S.last_path() == "mosaic"
     assert float((hr - hr_t).abs().max()) < 5e-4
     np.testing.assert_allclose(errs.cpu().numpy(), e_t.cpu().numpy(), rtol=2e-6)
+    for _ in range(4):  # the same bits from call to call
+        hr_r, errs_r = S.ibp_batched(lr, shifts, psf, saa, f, 80, 0.5)
+        assert torch.equal(hr_r, hr) and torch.equal(errs_r, errs)
 
 
 def test_patch_kernel_in_place_batches_and_fallbacks():
@@ -723,7 +736,10 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert hr2.data_ptr() == buf.data_ptr() and torch.equal(hr, hr2) and torch.equal(errs, errs2)
     one, e1 = S.ibp_batched(lr_d[3:4], shifts, psf, saa_d[3:4], f, 12, 0.5)
     assert torch.equal(one[0], hr[3]) and torch.equal(e1[0], errs[3])
-    S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # non-separable PSF
+    S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # a PSF that is not rank 1: the kernel's 7 x 7 form
+    assert S.last_path() == "patch"
+    dup = shifts + [shifts[5]]                                                              # ... but not with a count plane (two frames on one phase)
+    S.ibp_batched(torch.cat([lr_d[:1], lr_d[:1, 5:6]], dim=1), dup, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)
     assert S.last_path() == "mosaic"
     S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR: the two-launch window kernels
     assert S.last_path() == "atile"
