@@ -206,8 +206,8 @@ def measure(S, synth, lib, wl, prec, steps, warmup, seed_base, barrier=None, all
     per_iter = {k: v["avg_us"] for k, v in kernels.items() if v["launches"] == n_iter and k != "k_ibp_patch"}
     if "k_ibp_dtile" in kernels:  # a pair of launches per iteration (byte / float form of the mosaic: an item is iterated by exactly one)
         per_iter["k_ibp_dtile"] = kernels["k_ibp_dtile"]["total_ms"] * 1e3 / n_iter
-    for kn in ("k_ibp_sv", "k_ibp_sh"):  # float64 strips: n_iter + 1 vertical launches (the first and the last do half the work), a pair of
-        if kn in kernels:                 # horizontal launches per iteration (byte / float form of the mosaic)
+    for kn in ("k_ibp_sv", "k_ibp_sh"):  # float64 strips: the batch in chunks, n_iter + 1 vertical launches (the first and the last do half the
+        if kn in kernels:                 # work) and n_iter horizontal ones per chunk
             per_iter[kn] = kernels[kn]["total_ms"] * 1e3 / n_iter
     if "k_ibp_patch" in kernels:  # all iterations of a patch in one launch
         per_iter["k_ibp_patch"] = kernels["k_ibp_patch"]["total_ms"] * 1e3 / n_iter

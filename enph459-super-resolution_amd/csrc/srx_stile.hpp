@@ -419,19 +419,16 @@ __global__ void __launch_bounds__(256, 2)
 // =====================================================================================================================================
 // k_ibp_sh: grid (4 row strips, B), block 256.  Lane = plane row q = 64 strip + lane (natural row gy = q - exy), wave u = columns 64 u ...
 // =====================================================================================================================================
+// The LR mosaic as bytes when every far-field sample of the patch is an integer in [0, 255] (k_stile_prep's flag), else as T: two instantiations of
+// the body behind ONE workgroup-uniform branch at the very top of the kernel (k_ibp_dtile's arrangement: two whole bodies share no live range).
+// As a run-time choice inside one body -- even per group of eight columns, feeding the same arithmetic -- the allocator spilled 92 registers where
+// either form alone spills 1; as a pair of launches (k_ibp_patch's arrangement) the empty twin cost 4.8 us per chunk and iteration, 5 % of the loop.
 template <typename T, bool C01, bool M8>
-__global__ void __launch_bounds__(256, 2)
-    k_ibp_sh(T *P, const STabs<T> tb, const patch::PatchArgs pa, const AxW<T> aw, double *__restrict__ epart,
-             int want_err)
+__device__ __forceinline__ void sh_body(float *lds, T *P, const STabs<T> &tb, const patch::PatchArgs &pa, const AxW<T> &aw, double *__restrict__ epart,
+                                        int want_err)
 {
-    __shared__ float lds[4 * RW + STRIP_T * (sizeof(T) / 4) + 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.x, b = blockIdx.y;
-    // the LR mosaic as bytes when every far-field sample of the patch is an integer in [0, 255] (k_stile_prep's flag), else as T: two
-    // instantiations launched one after the other, a patch is taken by exactly one (as a run-time choice inside one kernel -- even per
-    // group of eight columns, feeding the same arithmetic -- the allocator spilled 92 registers where either form alone spills 4)
-    if ((__builtin_amdgcn_readfirstlane(tb.m8[b]) != 0) != M8)
-        return;
     constexpr bool m8 = M8;
     T *Rown = reinterpret_cast<T *>(lds + u * RW);
     const T *Rlf = reinterpret_cast<const T *>(lds + (u - 1) * RW), *Rrt = reinterpret_cast<const T *>(lds + (u + 1) * RW);
@@ -617,6 +614,17 @@ __global__ void __launch_bounds__(256, 2)
     }
 }
 
+template <typename T, bool C01>
+__global__ void __launch_bounds__(256, 2)
+    k_ibp_sh(T *P, const STabs<T> tb, const patch::PatchArgs pa, const AxW<T> aw, double *__restrict__ epart, int want_err)
+{
+    __shared__ float lds[4 * RW + STRIP_T * (sizeof(T) / 4) + 16];
+    if (__builtin_amdgcn_readfirstlane(tb.m8[blockIdx.y]) != 0)
+        sh_body<T, C01, true>(lds, P, tb, pa, aw, epart, want_err);
+    else
+        sh_body<T, C01, false>(lds, P, tb, pa, aw, epart, want_err);
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------------------
 template <typename T> static inline void fill_axis(const mosaic::AxisPlan &pl, int N, const T *cfwd, const T *cbwd, patch::AxisC &ax, AxW<T> &aw)
 {
@@ -696,13 +704,10 @@ static int iterate(const T *hr_init, T *hr, int B, int N, int f, const mosaic::A
         const dim3 grid(4, nb), blk(256);
         SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr_init + po, hr + po, P + po, awy, pa.y.ex, sn, 1, ep, vt, scale, er, n_iter, 0);
         for (int it = 0; it < n_iter; it++) {
-            if (pa.c01) {
-                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, true>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
-                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true, false>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
-            } else {
-                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, true>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
-                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false, false>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
-            }
+            if (pa.c01)
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, true>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
+            else
+                SRX_LAUNCH(KID_IBP_SH, (k_ibp_sh<T, false>), grid, blk, 0, st, P + po, tb, pa, awx, ep, want);
             SRX_LAUNCH(KID_IBP_SV, (k_ibp_sv<T>), grid, blk, 0, st, hr + po, hr + po, P + po, awy, pa.y.ex, sn, it == n_iter - 1 ? 2 : 0, ep, vt, scale, er,
                        n_iter, it);
         }
