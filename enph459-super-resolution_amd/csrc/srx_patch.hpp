@@ -150,11 +150,13 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
     // call on two of four configurations (tools/dev/pt_check.py; not understood: the tile kernels keep those))
     if (!((kc.separable || !rank1_only) && axis_ok(py, N, f) && axis_ok(px, N, f)))
         return false;
+#ifndef SRX_PATCH_7X7_ANY  // (diagnostic builds: the 7 x 7 form on count planes too -- tools/dev/pt_check.py)
     if (!kc.separable) {
         unsigned long long ry[4], rx[4];
         if (!c01_masks(py, px, N, f, ry, rx))
             return false;
     }
+#endif
     // the near band within the kernel's two-pixels-per-thread descriptor lists (iterate() computes the same count)
     auto span = [&](const mosaic::AxisPlan &pl, int &ex, int &nb) {
         int nmin = pl.n[0], nmax = pl.n[0];
@@ -1503,8 +1505,10 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, true, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);  \
         SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, false, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter); \
     } while (0)
+#ifndef SRX_PATCH_7X7_ANY
     if (psf != 0 && !pa.c01)
         return SRX_E_UNSUPPORTED;  // (eligible() keeps these on the tile kernels)
+#endif
     if (pa.c01) {
         if (psf == 0)
             SRX_PATCH_PAIR(true, 0);
@@ -1513,7 +1517,14 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         else
             SRX_PATCH_PAIR(true, 3);
     } else {
-        SRX_PATCH_PAIR(false, 0);
+#ifdef SRX_PATCH_7X7_ANY
+        if (psf == 2)
+            SRX_PATCH_PAIR(false, 2);
+        else if (psf == 3)
+            SRX_PATCH_PAIR(false, 3);
+        else
+#endif
+            SRX_PATCH_PAIR(false, 0);
     }
 #undef SRX_PATCH_PAIR
     return SRX_OK;
