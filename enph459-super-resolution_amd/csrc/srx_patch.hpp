@@ -125,7 +125,6 @@ struct PatchTabs {
 };
 
 // ---- eligibility ----------------------------------------------------------------------------------------------------
-static inline bool c01_masks(const mosaic::AxisPlan &py, const mosaic::AxisPlan &px, int N, int f, unsigned long long ry[4], unsigned long long rx[4]);
 static inline bool axis_ok(const mosaic::AxisPlan &pl, int N, int f)
 {
     int nmin = pl.n[0], nmax = pl.n[0];
@@ -145,18 +144,9 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
         return false;
     fused::Kernel7<float> kc;
     fused::make_kernel7<float>(k, kh, kw, false, kc);
-    // (round 4: a PSF that is not rank 1 runs the 7 x 7 form of the two blurs, blur2d_pass1 / blur2d_fix -- on full phase grids, i.e. count maps
-    // that are 0/1 products; with a count PLANE (frames sharing a phase, lattices) the 7 x 7 instantiations gave results that changed from call to
-    // call on two of four configurations (tools/dev/pt_check.py; not understood: the tile kernels keep those))
+    // (round 4: a PSF that is not rank 1 runs the 7 x 7 form of the two blurs, blur2d_pass1 / blur2d_fix)
     if (!((kc.separable || !rank1_only) && axis_ok(py, N, f) && axis_ok(px, N, f)))
         return false;
-#ifndef SRX_PATCH_7X7_ANY  // (diagnostic builds: the 7 x 7 form on count planes too -- tools/dev/pt_check.py)
-    if (!kc.separable) {
-        unsigned long long ry[4], rx[4];
-        if (!c01_masks(py, px, N, f, ry, rx))
-            return false;
-    }
-#endif
     // the near band within the kernel's two-pixels-per-thread descriptor lists (iterate() computes the same count)
     auto span = [&](const mosaic::AxisPlan &pl, int &ex, int &nb) {
         int nmin = pl.n[0], nmax = pl.n[0];
@@ -809,41 +799,36 @@ __device__ __forceinline__ void blur2d_pass1(float (&a)[64], const float (&hl)[3
         for (int j = 0; j < 3; j++)
             w[NB + 3 + j] = j0 + NB + j < 64 ? a[j0 + NB + j] : hr[j];
         c0 = w[NB], c1 = w[NB + 1], c2 = w[NB + 2];
-        f2 pw[NB + 5];  // (x, x + 1) for every x of the window
+        // (scalar multiply-adds, not k_ibp_ztile's packed pairs: with four waves per SIMD a v_pk_fma_f32 costs the SIMD what two v_fma_f32 do, and the
+        // pairs (w[m], w[m + 1]) of BOTH alignments tie the plane's registers into 64-bit tuples all the way back through the chains of stage C:
+        // 57 / 77 spilled registers and 0.32 GB of scratch traffic per C2 iteration in the packed form -- same time, 220 us.  The packed form's
+        // count-PLANE instantiations (103 spilled registers) also gave results that changed from call to call on two of four configurations of
+        // tools/dev/pt_check.py -- not a race (extra barriers changed nothing), no unwritten table (NaN poisoning left no NaN), never understood;
+        // this form has 1 - 2 spilled registers and passes all of them)
 #pragma unroll
-        for (int m = 0; m < NB + 5; m++)
-            pw[m] = (f2){w[m], w[m + 1]};
-#pragma unroll
-        for (int j = 0; j < NB; j += 2) {
-            f2 t[7];
+        for (int j = 0; j < NB; j++) {
+            float t[7];
 #pragma unroll
             for (int c = LO; c <= HI; c++) {
-                t[c] = (f2){kw[c][LO], kw[c][LO]} * pw[j + LO];
+                t[c] = kw[c][LO] * w[j + LO];
 #pragma unroll
                 for (int r = LO + 1; r <= HI; r++)
-                    t[c] = __builtin_elementwise_fma((f2){kw[c][r], kw[c][r]}, pw[j + r], t[c]);
+                    t[c] = fmaf(kw[c][r], w[j + r], t[c]);
             }
-            float o[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                float u1, u2, u3, d1, d2, d3, res;
-                if (RAD == 3) {
-                    u1 = h ? t[0].y : t[0].x, d1 = h ? t[6].y : t[6].x;
-                    u2 = (h ? t[1].y : t[1].x) + lane_up(u1), d2 = (h ? t[5].y : t[5].x) + lane_dn(d1);
-                    u3 = (h ? t[2].y : t[2].x) + lane_up(u2), d3 = (h ? t[4].y : t[4].x) + lane_dn(d2);
-                    res = ((h ? t[3].y : t[3].x) + lane_up(u3)) + lane_dn(d3);
-                } else {  // the missing first stage: U1 = D1 = 0
-                    u1 = 0.f, d1 = 0.f;
-                    u2 = h ? t[1].y : t[1].x, d2 = h ? t[5].y : t[5].x;
-                    u3 = (h ? t[2].y : t[2].x) + lane_up(u2), d3 = (h ? t[4].y : t[4].x) + lane_dn(d2);
-                    res = ((h ? t[3].y : t[3].x) + lane_up(u3)) + lane_dn(d3);
-                }
-                o[h] = res;
-                const f4 ev = lane == 0 ? (f4){d1, d2, d3, 0.f} : (f4){u1, u2, u3, 0.f};
-                edst[(j0 + j + h) * estr] = ev;
+            float u1, u2, u3, d1, d2, d3;
+            if (RAD == 3) {
+                u1 = t[0], d1 = t[6];
+                u2 = t[1] + lane_up(u1), d2 = t[5] + lane_dn(d1);
+            } else {  // the missing first stage: U1 = D1 = 0
+                u1 = 0.f, d1 = 0.f;
+                u2 = t[1], d2 = t[5];
             }
-            a[j0 + j] = o[0], a[j0 + j + 1] = o[1];
-            asm volatile("" : "+v"(a[j0 + j]), "+v"(a[j0 + j + 1]));  // (as in k_ibp_ztile: the last adds of a pixel stay with its arithmetic)
+            u3 = t[2] + lane_up(u2), d3 = t[4] + lane_dn(d2);
+            const float res = (t[3] + lane_up(u3)) + lane_dn(d3);
+            const f4 ev = lane == 0 ? (f4){d1, d2, d3, 0.f} : (f4){u1, u2, u3, 0.f};
+            edst[(j0 + j) * estr] = ev;
+            a[j0 + j] = res;
+            asm volatile("" : "+v"(a[j0 + j]));  // (as in k_ibp_ztile: the last adds of a pixel stay with its arithmetic)
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1505,10 +1490,6 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, true, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter);  \
         SRX_LAUNCH(KID_IBP_PATCH, (k_ibp_patch<C01_, false, PSF_>), dim3(B), dim3(1024), 0, st, hr_init, hr, tb, pa, Vtot, scale, errors, n_iter); \
     } while (0)
-#ifndef SRX_PATCH_7X7_ANY
-    if (psf != 0 && !pa.c01)
-        return SRX_E_UNSUPPORTED;  // (eligible() keeps these on the tile kernels)
-#endif
     if (pa.c01) {
         if (psf == 0)
             SRX_PATCH_PAIR(true, 0);
@@ -1517,14 +1498,12 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         else
             SRX_PATCH_PAIR(true, 3);
     } else {
-#ifdef SRX_PATCH_7X7_ANY
-        if (psf == 2)
-            SRX_PATCH_PAIR(false, 2);
-        else if (psf == 3)
-            SRX_PATCH_PAIR(false, 3);
-        else
-#endif
+        if (psf == 0)
             SRX_PATCH_PAIR(false, 0);
+        else if (psf == 2)
+            SRX_PATCH_PAIR(false, 2);
+        else
+            SRX_PATCH_PAIR(false, 3);
     }
 #undef SRX_PATCH_PAIR
     return SRX_OK;

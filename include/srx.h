@@ -73,7 +73,7 @@ typedef enum {
 int srx_version(void);
 const char *srx_strerror(int status);
 /* Name of the code path the last srx_ibp_* / srx_saa_* call on this thread took:
- * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch; any 7x7 PSF on full phase grids), "ztile" (mosaic
+ * "patch" (mosaic formulation, a whole 256x256 HR patch per workgroup, all iterations in one launch; any 7x7 PSF), "ztile" (mosaic
  * formulation at integer HR shifts on frames of at least 128x128: one launch per iteration on register-resident tiles),
  * "ctile" (the same in float64, rank-1 PSF), "stile" (float64, a common fraction > 0, 256x256 HR patches: two launches per iteration on
  * register-resident strips that span the patch in the direction their operators run), "dtile" (a common fraction > 0 on frames of at least 256x256: one launch per iteration on

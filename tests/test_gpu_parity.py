@@ -689,6 +689,9 @@ PATCH_CFGS_7X7 = {
     "x4_grid_full7": (4, synth.phase_shifts(4), True, "full7"),
     "x4_grid_float_asym": (4, synth.phase_shifts(4), False, "asym"),
     "x4_sub12_full7": (4, [s for s in synth.phase_shifts(4) if s[0] > -0.3], False, "full7"),  # a 3 x 4 product grid, non-integer frames
+    "x4_dup_full7": (4, synth.phase_shifts(4) + [synth.phase_shifts(4)[5]], True, "full7"),    # a count plane (two frames on one phase)
+    "x4_lattice_float_full7": (4, [synth.phase_shifts(4)[i] for i in (0, 5, 6, 15)], False, "full7"),  # a lattice that is no product, float mosaic
+    "x4_dup_float_asym": (4, synth.phase_shifts(4) + [synth.phase_shifts(4)[5]], False, "asym"),
     "x2_grid_asym": (2, synth.phase_shifts(2), True, "asym"),
     "x2_half_row_full7": (2, [(0.25, 0.25), (0.25, -0.25)], False, "full7"),
 }
@@ -738,9 +741,9 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert torch.equal(one[0], hr[3]) and torch.equal(e1[0], errs[3])
     S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # a PSF that is not rank 1: the kernel's 7 x 7 form
     assert S.last_path() == "patch"
-    dup = shifts + [shifts[5]]                                                              # ... but not with a count plane (two frames on one phase)
+    dup = shifts + [shifts[5]]                                                              # ... also with a count plane (two frames on one phase)
     S.ibp_batched(torch.cat([lr_d[:1], lr_d[:1, 5:6]], dim=1), dup, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)
-    assert S.last_path() == "mosaic"
+    assert S.last_path() == "patch"
     S.ibp_batched(lr_d[:1, :, :32, :32], shifts, psf, saa_d[:1, :128, :128], f, 2, 0.5)    # 128 x 128 HR: the two-launch window kernels
     assert S.last_path() == "atile"
     S.ibp_batched(lr_d[:1].double(), shifts, psf, saa_d[:1].double(), f, 2, 0.5, precision="f64")

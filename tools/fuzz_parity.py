@@ -25,7 +25,8 @@ def random_case(rng):
         grid = synth.phase_shifts(f)
         N = int(rng.integers(2, len(grid) + 1))
         idx = rng.choice(len(grid), size=N, replace=False)
-        return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], 256 // f, 256 // f, synth.gaussian_psf(), int(rng.integers(1, 6)), kind
+        psf = [synth.gaussian_psf(), synth.gaussian_psf(), synth.asymmetric_psf(), synth.full_support_psf()][int(rng.integers(0, 4))]  # (round 4: its 7 x 7 forms too)
+        return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], 256 // f, 256 // f, psf, int(rng.integers(1, 6)), kind
     if kind == "window":     # k_ibp_dtile's domain: a common fraction > 0 on a frame of at least 256 rows x 192 columns (HR), rows in quads, columns
         f = int(rng.choice([2, 4]))  # in groups of 16; a subset of a phase grid (byte mosaic + 0/1 masks) or, one time in three, non-integer frames
         grid = synth.phase_shifts(f)
