@@ -223,7 +223,8 @@ static size_t ibp_ws_composed(int eb, int B, int N, int h, int w, int H, int W, 
     const size_t P = align_up((size_t)B * H * W * eb);
     const size_t sh = cdiv(H, f), sw = cdiv(W, f);
     return 5 * P + 2 * align_up((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD) * eb) +
-           2 * align_up((size_t)B * sh * sw * eb) + (size_t)4 * N * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>));
+           2 * align_up((size_t)B * sh * sw * eb) + (size_t)4 * N * align_up((size_t)(H > W ? H : W) * sizeof(AxisTap<double>)) +
+           align_up((size_t)B * cdiv((int)sw, 64) * cdiv((int)sh, 4) * sizeof(double));  // k_residual's block partials
 }
 
 template <typename T>
@@ -243,6 +244,8 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
     const size_t tl = (size_t)(H > W ? H : W);
     for (int i = 0; i < 4 * N; i++)
         taps[i] = ar.take<AxisTap<T>>(tl);
+    const int rblk = cdiv(mw, 64) * cdiv(mh, 4);
+    double *rpart = ar.take<double>((size_t)B * rblk);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     const int Hp = H + 2 * SRX_NPAD, Wp = W + 2 * SRX_NPAD;
@@ -266,9 +269,12 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
             SRX_TRY(shift_sampled(b, B, H, W, 0, 0, f, sh, sw, sim, false, pad, scr, taps[4 * q], taps[4 * q + 1], true,
                                   st));
             hipLaunchKernelGGL(k_residual<T>, dim3(cdiv(mw, 64), cdiv(mh, 4), B), dim3(64, 4), 0, st,
-                               lr + (size_t)q * h * w, (size_t)N * h * w, w, sim, (size_t)sh * sw, sw, mh, mw, err,
-                               errors ? errors + it : nullptr, n_iter, scale);
+                               lr + (size_t)q * h * w, (size_t)N * h * w, w, sim, (size_t)sh * sw, sw, mh, mw, err, errors ? rpart : nullptr);
             SRX_CHECK_LAUNCH();
+            if (errors) {
+                hipLaunchKernelGGL(k_residual_reduce, dim3(B), dim3(256), 0, st, rpart, rblk, errors + it, n_iter, scale);
+                SRX_CHECK_LAUNCH();
+            }
             hipLaunchKernelGGL(k_zero_insert<T>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(64, 4), 0, st, err, mh, mw, f, H,
                                W, up);
             SRX_CHECK_LAUNCH();

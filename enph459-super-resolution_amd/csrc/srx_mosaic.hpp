@@ -207,7 +207,7 @@ template <typename T, int IB, int PXT>
 __global__ void __launch_bounds__(256)
     k_mosaic_build(const T *__restrict__ lr, int B, int N, int h, int w, const MTap *__restrict__ tabY,
                    const MTap *__restrict__ tabX, int Hg, int Wg, int PBy, int PBx, int Dy, int Dx, int NB,
-                   T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vtot, int tr_lo, int tr_hi)
+                   T *__restrict__ Mg, T *__restrict__ Cg, T *__restrict__ Mu, double *__restrict__ Vpart, int tr_lo, int tr_hi)
 {
     __shared__ double part[4][IB];
     const int q0 = blockIdx.x * 64 * PXT + threadIdx.x, p = blockIdx.y * 4 + threadIdx.y, b0 = blockIdx.z * IB;
@@ -291,10 +291,18 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (threadIdx.y == 0 && threadIdx.x < IB && b0 + threadIdx.x < B) {
         const int i = threadIdx.x;
-        const double s = part[0][i] + part[1][i] + part[2][i] + part[3][i];
-        if (s != 0.0)
-            atomicAdd(&Vtot[b0 + i], s);
+        // one partial per block and item, summed in a fixed order by k_vtot_reduce (round 4: as one atomicAdd per block the constant part of
+        // the MSE trace -- and with it every entry of the trace -- changed in its last bits from call to call whenever the sums were inexact:
+        // frames that are not integers, several frames on one phase.  tools/dev/zt_determinism.py)
+        Vpart[(size_t)(b0 + i) * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
     }
+}
+
+// Vtot[b] = the sum of item b's block partials, in a fixed order.  grid B, block 256
+__global__ void __launch_bounds__(256) k_vtot_reduce(const double *__restrict__ Vpart, int nblk, double *__restrict__ Vtot)
+{
+    __shared__ double part4[4];
+    err_trace_reduce(Vpart, nblk, blockIdx.x, 0.0, Vtot + blockIdx.x, threadIdx.x, part4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1183,6 +1191,7 @@ static inline size_t ws_common(int eb, int B, int N, int H, int W)
     const size_t NS = (N + 3) & ~3;
     return align_up((size_t)B * Hg * Wg * eb) + align_up(Hg * Wg * eb) + align_up((size_t)B * NBmax * eb) +
            2 * align_up((size_t)N * (Hg > Wg ? Hg : Wg) * sizeof(MTap)) + align_up((size_t)B * sizeof(double)) +
+           align_up((size_t)B * cdiv((int)Wg, 64) * cdiv((int)Hg, 4) * sizeof(double)) +  // k_mosaic_build's block partials of V
            align_up(NBmax * sizeof(int)) + align_up(NBmax * NS * sizeof(int));
 }
 
@@ -1260,6 +1269,7 @@ static int common_prep(Common<T> &c, Impl impl, const T *lr, int B, int N, int h
     T *Mu = c.Mu = ar.take<T>((size_t)B * NB);
     MTap *tabY = c.tabY = ar.take<MTap>((size_t)N * Hg), *tabX = c.tabX = ar.take<MTap>((size_t)N * Wg);
     double *Vtot = c.Vtot = ar.take<double>(B);
+    double *Vpart = ar.take<double>((size_t)B * cdiv(Wg, 64) * cdiv(Hg, 4));
     int *ncu = c.ncu = ar.take<int>(NB), *nyx = c.nyx = ar.take<int>((size_t)NB * NS);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
@@ -1298,12 +1308,16 @@ static int common_prep(Common<T> &c, Impl impl, const T *lr, int B, int N, int h
     if constexpr (sizeof(T) == 4)
         c.own_build = impl == IMPL_PATCH && patch::builds_itself(py, px, N, f);
     if (c.own_build) {
-    } else if (B >= 8)
-        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h,
-                   w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot, tr_lo, tr_hi);
-    else
-        SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1, 4>), dim3(cdiv(Wg, 256), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w,
-                   tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vtot, tr_lo, tr_hi);
+    } else {
+        if (B >= 8)
+            SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 8, 1>), dim3(cdiv(Wg, 64), cdiv(Hg, 4), cdiv(B, 8)), dim3(64, 4), 0, st, lr, B, N, h,
+                       w, tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vpart, tr_lo, tr_hi);
+        else
+            SRX_LAUNCH(KID_MOSAIC_BUILD, (k_mosaic_build<T, 1, 4>), dim3(cdiv(Wg, 256), cdiv(Hg, 4), B), dim3(64, 4), 0, st, lr, B, N, h, w,
+                       tabY, tabX, Hg, Wg, py.PB, px.PB, py.D, px.D, NB, Mg, Cg, Mu, Vpart, tr_lo, tr_hi);
+        hipLaunchKernelGGL(k_vtot_reduce, dim3(B), dim3(256), 0, st, Vpart, (B >= 8 ? cdiv(Wg, 64) : cdiv(Wg, 256)) * cdiv(Hg, 4), Vtot);
+        SRX_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_build_near, dim3(cdiv(NB, 256)), dim3(256), 0, st, tabY, tabX, N, NS, Hg, Wg, py.PB, px.PB, py.D, px.D,
                        NB, ncu, nyx);
     SRX_CHECK_LAUNCH();

@@ -546,11 +546,13 @@ template <typename T> __global__ void __launch_bounds__(256) k_div(T *__restrict
 
 static inline int grid1d(size_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
-// err = lr[:mh,:mw] - sim[:mh,:mw]; errors[b] += sum(err^2) * scale     (run_sr.py:199-202)
+// err = lr[:mh,:mw] - sim[:mh,:mw]; rpart[b][block] = the block's sum(err^2)     (run_sr.py:199-202)
+// (round 4: one partial per block, added to the trace in a fixed order by k_residual_reduce -- as one atomicAdd per block the composed path's
+// MSE trace changed in its last bits from call to call)
 template <typename T>
 __global__ void __launch_bounds__(256)
     k_residual(const T *__restrict__ lr, size_t lr_item_stride, int w, const T *__restrict__ sim, size_t sim_item_stride,
-               int sw, int mh, int mw, T *__restrict__ err, double *__restrict__ errors, int errors_stride, double scale)
+               int sw, int mh, int mw, T *__restrict__ err, double *__restrict__ rpart)
 {
     __shared__ double part[4];
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
@@ -565,8 +567,17 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0)
         part[threadIdx.y] = sq;
     __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0 && errors)
-        atomicAdd(&errors[(size_t)b * errors_stride], (part[0] + part[1] + part[2] + part[3]) * scale);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && rpart)
+        rpart[(size_t)b * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// errors[b * stride] += scale * (item b's block partials, in a fixed order).  grid B, block 256
+__global__ void __launch_bounds__(256) k_residual_reduce(const double *__restrict__ rpart, int nblk, double *__restrict__ errors, int errors_stride, double scale)
+{
+    __shared__ double part4[4];
+    __shared__ double total;
+    err_trace_reduce(rpart, nblk, blockIdx.x, 0.0, &total, threadIdx.x, part4);
+    if (threadIdx.x == 0)
+        errors[(size_t)blockIdx.x * errors_stride] += total * scale;
 }
 
 // hr = clip(hr + step * corr / n, 0, 255)   (run_sr.py:204-205)
