@@ -38,5 +38,13 @@ check("strips x4 dup, float", "f64", rough(6, 17, 64, 64) * 0.75 + 0.3, P4 + [P4
 check("frame, float64 (40-row regions)", "f64", rough(1, 5, 300, 400) * 0.75 + 0.3, synth.NOMINAL_5, synth.gaussian_psf(), 2, 3, "ctile")
 check("frame, 5x5 core of a 7x7", "f32", rough(1, 5, 600, 800) * 0.75 + 0.3, synth.NOMINAL_5, synth.asymmetric_psf(), 2, 3, "ztile")
 check("frame, full 7x7", "f32", rough(1, 5, 600, 800), synth.NOMINAL_5, synth.full_support_psf(), 2, 3, "ztile")
+# the older register-resident kernels with frames that are not integers (state AND trace)
+check("x4 frame, 16 phases, float (windows)", "f32", rough(1, 16, 80, 100) * 0.75 + 0.3, P4, synth.gaussian_psf(), 4, 3, "dtile")
+check("x4 small frame, float (two-launch)", "f32", rough(2, 16, 40, 50) * 0.75 + 0.3, P4, synth.gaussian_psf(), 4, 3, "atile")
+check("x2 measured shifts, float", "f32", rough(2, 4, 150, 277) * 0.75 + 0.3, synth.MEASURED_4, synth.gaussian_psf(), 2, 3, "btile")
+check("x2 measured shifts, asym PSF, float", "f32", rough(2, 4, 150, 277) * 0.75 + 0.3, synth.MEASURED_4, synth.asymmetric_psf(), 2, 3, "btile")
+check("x4 patch, gaussian, float", "f32", rough(6, 16, 64, 64) * 0.75 + 0.3, P4, synth.gaussian_psf(), 4, 3, "patch")
+check("x3 free shifts, float (tile kernels)", "f32", rough(1, 3, 60, 70) * 0.75 + 0.3, [(0.1, -0.2), (-0.3, 0.25), (0.4, 0.05)], synth.gaussian_psf(), 3, 3, "fused")
+check("x2 free shifts, float64 (tile kernels)", "f64", rough(1, 3, 60, 70) * 0.75 + 0.3, [(0.1, -0.2), (-0.3, 0.25), (0.4, 0.05)], synth.gaussian_psf(), 2, 3, "fused")
 print("TOTAL deviating:", bad_total)
 sys.exit(1 if bad_total else 0)
