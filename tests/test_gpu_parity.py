@@ -749,6 +749,9 @@ def test_patch_kernel_in_place_batches_and_fallbacks():
     assert torch.equal(one[0], hr[3]) and torch.equal(e1[0], errs[3])
     S.ibp_batched(lr_d[:1], shifts, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)          # a PSF that is not rank 1: the kernel's 7 x 7 form
     assert S.last_path() == "patch"
+    h7, e7 = S.ibp_batched(lr_d[:2], shifts, synth.full_support_psf(), saa_d[:2], f, 3, 0.5)
+    h7b, e7b = S.ibp_batched(lr_d[:2], shifts, synth.full_support_psf(), saa_d[:2], f, 3, 0.5, exact_workspace=False)  # shape-only arena
+    assert S.last_path() == "patch" and torch.equal(h7, h7b) and torch.equal(e7, e7b)
     dup = shifts + [shifts[5]]                                                              # ... also with a count plane (two frames on one phase)
     S.ibp_batched(torch.cat([lr_d[:1], lr_d[:1, 5:6]], dim=1), dup, synth.asymmetric_psf(), saa_d[:1], f, 2, 0.5)
     assert S.last_path() == "patch"
@@ -814,6 +817,8 @@ def test_strip_kernels_f64_chunks_and_traceless_calls():
             assert torch.equal(one[0], hr[i]) and torch.equal(e1[0], errs[i]), i
         hr_n, none = S.ibp_batched(lr, shifts, psf, init, f, 3, 0.5, want_errors=False)
         assert none is None and torch.equal(hr_n, hr)
+        hr_b, errs_b = S.ibp_batched(lr[:3], shifts, psf, init[:3], f, 3, 0.5, exact_workspace=False)  # the arena sized by the shape-only bound
+        assert S.last_path() == "stile" and torch.equal(hr_b, hr[:3]) and torch.equal(errs_b, errs[:3])
         hr_0, _ = S.ibp_batched(lr[:2], shifts, psf, init[:2], f, 0, 0.5)
         assert torch.equal(hr_0, init[:2])
     finally:
