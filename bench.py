@@ -105,6 +105,9 @@ def workload(synth, name, batch, iters):
     if name == "c3_f4":    # "plus f=4 variant 768x1024 -> 3072x4096"
         return (4, (768, 1024), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1, iters or 80,
                 "C3-f4: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all 4x4 sub-pixel phases), Gaussian PSF")
+    if name == "c3_f4_measured":  # ... with a PSF that is not rank 1 (the 7 x 7 form of the window kernel)
+        return (4, (768, 1024), synth.phase_shifts(4), synth.asymmetric_psf(), batch or 1, iters or 80,
+                "C3-f4, --psf measured: 768x1024 LR -> 3072x4096 at x4, N=16 frames (all sub-pixel phases), asymmetric (non-separable) 7x7 PSF")
     if name == "c3_f4_float":  # the same with frames that are not 8-bit integers (rep means, calibrated frames): the float form of the mosaic
         return (4, (768, 1024), synth.phase_shifts(4), synth.gaussian_psf(), batch or 1, iters or 80,
                 FLOAT_FRAMES + "C3-f4, non-integer frames: 768x1024 LR -> 3072x4096 at x4, N=16 frames, Gaussian PSF")
@@ -308,7 +311,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: 1024 patches for c2, 1 frame for c3_*)")
     ap.add_argument("--iters", type=int, default=0, help="IBP iterations (default: the reference's 80; 50 for c3_rgb)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2_measured", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_rgb_measured", "c3_f4", "c3_f4_float"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_measured", "c3_mono", "c3_mono_measured", "c3_rgb", "c3_rgb_measured", "c3_f4", "c3_f4_float", "c3_f4_measured"],
                     help="c2 (default, the headline): 1024 x4 patches, N=16 phases; c3_mono / c3_rgb: the reference's own "
                          "full-frame shapes (mono_cal_target N=5 nominal f=2 3072x4096; rgb_cal_target N=4 measured f=2 1536x2048); "
                          "c3_f4: the x4 variant of SURVEY 8d, 768x1024 -> 3072x4096, all 16 phases")
@@ -388,7 +391,7 @@ def main():
                                       ("c3_mono_measured", "c3_mono_measured", "f32", None), ("c3_rgb_x8", "c3_rgb", "f32", 8),
                                       ("c3_rgb_measured", "c3_rgb_measured", "f32", None), ("c3_rgb_measured_x8", "c3_rgb_measured", "f32", 8),
                                       ("c3_rgb_f64", "c3_rgb", "f64", None), ("c3_f4_x8", "c3_f4", "f32", 8),
-                                      ("c3_f4_float", "c3_f4_float", "f32", None)):
+                                      ("c3_f4_float", "c3_f4_float", "f32", None), ("c3_f4_measured", "c3_f4_measured", "f32", None)):
             lw = workload(synth, wname, lb if lb else (args.batch if wname == "c2" and args.batch else None), args.iters if wname == "c2" else None)
             r = measure(S, synth, lib, lw, lprec, 2, 1, 7000)
             legs[tag] = {"workload": r["desc"], "dtype": lprec, "batch": r["B"], "n_iter": r["n_iter"], "path": r["path"],

@@ -77,6 +77,7 @@ struct DTabs {
     const uint2 *nent;      // [ngrp][ntabs][NN_PAD]
     const float2 *Mn;       // [B][ntabs][NN_PAD]
     int ntabs;
+    const float *k2;        // srx_patch.hpp's 7 x 7 weight tables (a PSF that is not rank 1)
 };
 
 // ---- host-side plan ----------------------------------------------------------------------------------------------------
@@ -158,7 +159,18 @@ static inline bool eligible(int elem_bytes, int N, int H, int W, const double *s
         return false;
     fused::Kernel7<float> kc;
     fused::make_kernel7<float>(k, kh, kw, false, kc);
-    if (!(kc.separable && patch::axis_ok(py, N, f) && patch::axis_ok(px, N, f)))
+    // (round 4: a PSF that is not rank 1 on the 12-wave windows, srx_patch.hpp's 7 x 7 form -- when its outer ring is zero, as the reference's
+    // measured PSF's is: 131 us per iteration on 3072 x 4096 at x4 against the tile kernels' 141; with full 7 x 7 support the windows take 164
+    // (53 - 71 spilled registers under the 168-register cap) and the tile kernels keep the call)
+    if (!kc.separable) {
+        bool ring0 = !(call_flags() & SRX_FLAG_DIAG_WIDE_WINDOWS);
+        for (int i = 0; i < 7; i++)
+            for (int e : {i, 42 + i, 7 * i, 7 * i + 6})
+                ring0 = ring0 && kc.k[e] == 0.f;
+        if (!ring0)
+            return false;
+    }
+    if (!(patch::axis_ok(py, N, f) && patch::axis_ok(px, N, f)))
         return false;
     Plan pl;
     if (!plan(H, W, pl))
@@ -331,7 +343,7 @@ __global__ void __launch_bounds__(NTHR)
 // The stages are k_ibp_patch's (srx_patch.hpp has the derivations); what differs is where the state comes from and goes to, the
 // operand planes' pitch, and that the MSE sum and the store are restricted to the pixels this window owns.
 // =========================================================================================================================
-template <bool C01, bool M8, int NSX>
+template <bool C01, bool M8, int NSX, int PSF>  // PSF: srx_patch.hpp's forms -- 0 rank 1, 3 full 7 x 7, 2 a 7 x 7 whose outer ring is zero
 __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__ hr_src, float *__restrict__ hr_dst, const DTabs &tb, const DArgs &da,
                                            double *__restrict__ epart, const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale,
                                            double *__restrict__ err_prev, int err_stride)
@@ -411,7 +423,26 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
 #pragma unroll
         for (int q = 0; q < 16; q++)
             ld4(rs_src, vcol, sql + q * W * 16, a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-        patch::blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
+        if (PSF == 0) {
+            patch::blur_block(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT0, lane, sload8(awy));
+        } else {  // round 4: srx_patch.hpp's 7 x 7 form (blur2d_pass1 / blur2d_fix), here on a window: what lies beyond a window edge is zero for
+                  // the blur as it is for the separable one (inside the halo nobody owns)
+            Rown[SLOT0 + lane] = a[0];
+            Rown[SLOT0 + 64 + lane] = a[1];
+            Rown[SLOT0 + 128 + lane] = a[2];
+            Rown[SLOT0 + 192 + lane] = a[61];
+            Rown[SLOT0 + 256 + lane] = a[62];
+            Rown[SLOT0 + 320 + lane] = a[63];
+            __syncthreads();
+            float hl[3] = {0.f, 0.f, 0.f}, hr[3] = {0.f, 0.f, 0.f};
+            if (s != 0)
+                hl[0] = Rup[SLOT0 + 192 + lane], hl[1] = Rup[SLOT0 + 256 + lane], hl[2] = Rup[SLOT0 + 320 + lane];
+            if (s != 3)
+                hr[0] = Rdn[SLOT0 + lane], hr[1] = Rdn[SLOT0 + 64 + lane], hr[2] = Rdn[SLOT0 + 128 + lane];
+            patch::blur2d_pass1<PSF == 2 ? 2 : 3>(a, hl, hr, Rown, lane, tb.k2);
+            __syncthreads();
+            patch::blur2d_fix<PSF == 2 ? 2 : 3>(a, u == 0, u == NSX - 1, Rown, Rlf, Rrt, lane, [](int) {}, [](int, float v) { return v; });
+        }
         __builtin_amdgcn_sched_barrier(0);
         patch::fwd_chain(a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1, SLOT0, lane, sload8(awy + 16), yex);
         __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +463,8 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
         const bool rownear = wrapped || gy < nby;
         const bool rowown = !wrapped && gy >= td.y0 && gy < td.y1;
         const float crow = C01 ? (float)((rmask >> lane) & 1ull) : 0.f;
-        patch::blur_block(r, u == 0, u == NSX - 1, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
+        if (PSF == 0)
+            patch::blur_block(r, u == 0, u == NSX - 1, Rown, Rlf, Rrt, SLOT0, lane, sload8(awx));
         __builtin_amdgcn_sched_barrier(0);
         float yexx = 0.f;  // Y[gy, -1] (u == 0)
         patch::fwd_chain(r, u == 0, u == NSX - 1, Rown, Rlf, Rrt, SLOT1, SLOT0, lane, sload8(awx + 16), yexx);
@@ -669,8 +701,9 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
             const float gtop = exx ? gexx : r[0];
             const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];
             const float gp1 = u == NSX - 1 ? 0.f : Rrt[SLOT1 + lane], gp2 = u == NSX - 1 ? 0.f : Rrt[SLOT1 + 64 + lane];
-            patch::bwd_chain(r, a, u == 0, u == NSX - 1, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop,
-                             [](int) {}, [](int, float v) { return v; });
+            float hlo[3], hhi[3];  // (unused here: the adjoint 7 x 7 runs once, in stage C)
+            patch::bwd_chain_x<PSF == 0>(r, a, u == 0, u == NSX - 1, Rown, Rlf, Rrt, SLOT0 + 384, SLOT0, lane, sload8(awx + 16), sload8(awx + 8), gm1, gp1, gp2, gtop,
+                                         [](int) {}, [](int, float v) { return v; }, hlo, hhi);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // every wave has read its neighbours' slots before the transposes overwrite them
@@ -696,8 +729,7 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
         // through an asm that also takes the last value the previous quarter produced (and clobbers memory): without that dependency
         // the loads -- pure reads -- are hoisted above the whole chain, all 64 rows at once, and the chain runs on spilled registers
         float dep = 0.f;
-        patch::bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop,
-                         [&](int q) {
+        auto mid = [&](int q) {
                              auto load16 = [&](float(&ld)[16], int bq) {
                                  int so = sq0;
                                  asm volatile("" : "+s"(so), "+v"(dep)::"memory");
@@ -711,13 +743,23 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
                                  load16(hv, 2);
                              else if (q == 2)
                                  load16(hw, 3);
-                         },
-                         [&](int i, float corr) {
+                         };
+        auto post = [&](int i, float corr) {
                              const float v = __builtin_amdgcn_fmed3f(fmaf(corr, sn, ((i >> 4) & 1) ? hw[i & 15] : hv[i & 15]), 0.f, 255.f);
                              if ((i & 15) == 15)
                                  dep = v;
                              return v;
-                         });
+                         };
+        if (PSF == 0) {
+            patch::bwd_chain(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, mid, post);
+        } else {
+            float hl[3], hr[3];
+            patch::bwd_chain_x<false>(r, a, s == 0, s == 3, Rown, Rup, Rdn, SLOT1 + 384, SLOT1, lane, sload8(awy + 16), sload8(awy + 8), gm1, gp1, gp2, gtop, [](int) {},
+                                      [](int, float v) { return v; }, hl, hr);
+            patch::blur2d_pass1<PSF == 2 ? 2 : 3>(a, hl, hr, Rown, lane, tb.k2 + 56);
+            __syncthreads();
+            patch::blur2d_fix<PSF == 2 ? 2 : 3>(a, u == 0, u == NSX - 1, Rown, Rlf, Rrt, lane, mid, post);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- store what this window owns: whole row quads (wave-uniform), the lane's column or nothing
         const int cc = 64 * u + lane;
@@ -737,16 +779,16 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
 // after the other and lets the blocks of the wrong one leave; per iteration that is a second launch of a full grid of workgroups --
 // 4.8 us + a gap on a 74 us kernel, C3-f4.  As a branch INSIDE the iteration the two G steps cost 40 spilled registers, srx_patch.hpp;
 // two whole bodies do not share a live range.)
-template <bool C01, int NSX>
+template <bool C01, int NSX, int PSF = 0>
 __global__ void __launch_bounds__(256 * NSX)
     k_ibp_dtile(const float *__restrict__ hr_src, float *__restrict__ hr_dst, DTabs tb, DArgs da, double *__restrict__ epart,
                 const double *__restrict__ eprev, const double *__restrict__ Vtot, double scale, double *__restrict__ err_prev, int err_stride)
 {
     __shared__ float lds[Lds<NSX>::WORDS];
     if (__builtin_amdgcn_readfirstlane(tb.m8[blockIdx.y]) != 0)
-        dtile_body<C01, true, NSX>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
+        dtile_body<C01, true, NSX, PSF>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
     else
-        dtile_body<C01, false, NSX>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
+        dtile_body<C01, false, NSX, PSF>(lds, hr_src, hr_dst, tb, da, epart, eprev, Vtot, scale, err_prev, err_stride);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
@@ -756,7 +798,7 @@ static inline size_t tabs_bytes(int B, int N, int H, int W)
     return 3 * align_up((size_t)B * plane * 4) + align_up((size_t)B * (W / 4) * H * 4) + align_up((size_t)B * 4) + align_up(plane * 4) +
            align_up(2 * sizeof(AxisW)) + align_up(ntiles * sizeof(TileD)) + 2 * align_up(64 * 4 * 8) + align_up(ntabs * 4) +
            align_up(ntabs * NN_PAD * 8) + align_up(ngrp * ntabs * NN_PAD * 8) + align_up((size_t)B * ntabs * NN_PAD * 8) +
-           2 * align_up((size_t)B * ntiles * 8);
+           2 * align_up((size_t)B * ntiles * 8) + align_up(112 * 4);
 }
 
 // windows and 0/1 count masks, built on the device from the two axis plans (by-value arguments: no host buffer, no copy)
@@ -798,11 +840,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-template <int NSX, bool C01>
+template <int NSX, bool C01, int PSF = 0>
 static int launch_iter(dim3 grid, hipStream_t st, const float *src, float *dst, const DTabs &tb, const DArgs &da, double *ep, const double *eprev,
                        const double *Vtot, double scale, double *err_prev, int stride)
 {
-    SRX_LAUNCH(KID_IBP_DTILE, (k_ibp_dtile<C01, NSX>), grid, dim3(256 * NSX), 0, st, src, dst, tb, da, ep, eprev, Vtot, scale, err_prev, stride);
+    SRX_LAUNCH(KID_IBP_DTILE, (k_ibp_dtile<C01, NSX, PSF>), grid, dim3(256 * NSX), 0, st, src, dst, tb, da, ep, eprev, Vtot, scale, err_prev, stride);
     return SRX_OK;
 }
 
@@ -827,8 +869,28 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     uint2 *nrec = ar.take<uint2>((size_t)ntabs * NN_PAD), *nent = ar.take<uint2>((size_t)ngrp * ntabs * NN_PAD);
     float2 *Mn = ar.take<float2>((size_t)B * ntabs * NN_PAD);
     double *ep0 = ar.take<double>((size_t)B * ntiles), *ep1 = ar.take<double>((size_t)B * ntiles);
+    float *k2 = ar.take<float>(112);
     if (!ar.ok)
         return SRX_E_WORKSPACE;
+    int psf = 0;
+    if (!(kc.separable && kt.separable)) {
+        if (pl.nsx != 3)
+            return SRX_E_UNSUPPORTED;
+        const double kq = -6.0 * patch::ZD;
+        bool ring0 = true;
+        for (int i = 0; i < 7; i++)
+            for (int e : {i, 42 + i, 7 * i, 7 * i + 6})
+                ring0 = ring0 && kc.k[e] == 0.f && kt.k[e] == 0.f;
+        psf = ring0 ? 2 : 3;
+        patch::K2Pair kv;
+        for (int c = 0; c < 7; c++)
+            for (int r = 0; r < 8; r++) {
+                kv.v[8 * c + r] = r < 7 ? (float)(kq * kq * (double)kc.k[7 * r + c]) : 0.f;
+                kv.v[56 + 8 * c + r] = r < 7 ? kt.k[7 * r + c] : 0.f;
+            }
+        hipLaunchKernelGGL(patch::k_patch_k2, dim3(1), dim3(128), 0, st, kv, k2);
+        SRX_CHECK_LAUNCH();
+    }
     DArgs da;
     da.H = H, da.W = W, da.tiles_x = pl.tx.n, da.tiles_y = pl.ty.n;
     patch::AxisWPair awp;
@@ -857,7 +919,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_dtile_copy_in, dim3(cdiv(W, 256), H / 4, B), dim3(256), 0, st, hr_init, H, W, s0);
     SRX_CHECK_LAUNCH();
-    DTabs tb{Mt, Mt8, m8, Ct, aw, tiles, rowm, colm, nnt, nrec, nent, Mn, ntabs};
+    DTabs tb{Mt, Mt8, m8, Ct, aw, tiles, rowm, colm, nnt, nrec, nent, Mn, ntabs, k2};
     const dim3 grid(ntiles, B);
     for (int it = 0; it < n_iter; it++) {
         const float *src = (it & 1) ? s1 : s0;
@@ -869,6 +931,11 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         if (pl.nsx == 4)
             rc = da.c01 ? launch_iter<4, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
                         : launch_iter<4, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
+        else if (psf == 2)
+            rc = da.c01 ? launch_iter<3, true, 2>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
+                        : launch_iter<3, false, 2>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);
+        else if (psf == 3)
+            rc = SRX_E_UNSUPPORTED;  // (eligible() keeps full 7 x 7 support on the tile kernels)
         else
             rc = da.c01 ? launch_iter<3, true>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter)
                         : launch_iter<3, false>(grid, st, src, dst, tb, da, e, eprev, Vtot, scale, eo, n_iter);

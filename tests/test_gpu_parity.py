@@ -859,6 +859,11 @@ DTILE_CFGS = {
     "x4_n01": (4, [s for s in _PH4 if s[0] > 0 and s[1] > 0], (80, 100), 0, True),       # n in {0, 1}: samples above the image, no near band inside
     "x4_sub12": (4, [s for s in _PH4 if s[0] > -0.3], (80, 100), "wide", True),           # 3 x 4 product grid
     "x4_lattice": (4, [_PH4[0], _PH4[5], _PH4[6], _PH4[6], _PH4[15]], (64, 112), 0, False),  # two frames on one phase: the count plane
+    # round 4: PSFs that are not rank 1 (srx_patch.hpp's 7 x 7 form on the windows)
+    "x4_ph16_asym": (4, _PH4, (80, 100), 0, True, "asym"),                # 5 x 5 core (the reference's measured PSF has that support)
+    "x4_ph16_3x3win_asym": (4, _PH4, (160, 176), 0, False, "asym"),       # interior windows, float mosaic
+    "x2_ph4_asym": (2, synth.phase_shifts(2), (150, 232), 0, True, "asym"),
+    "x4_lattice_asym": (4, [_PH4[0], _PH4[5], _PH4[6], _PH4[6], _PH4[15]], (64, 112), 0, False, "asym"),  # count plane
 }
 
 
@@ -868,9 +873,9 @@ def test_frame_fraction_kernel_vs_oracle(cfg):
     tile kernels it replaces, in place, and as a batch."""
     from oracle import sr_oracle as O
     S.set_precision("f32")
-    f, shifts, (h, w), fl, integer = DTILE_CFGS[cfg]
+    f, shifts, (h, w), fl, integer = DTILE_CFGS[cfg][:5]
     flags = S.FLAG_DIAG_WIDE_WINDOWS if fl == "wide" else S.FLAG_AUTO
-    psf = synth.gaussian_psf()
+    psf = {"gauss": synth.gaussian_psf(), "asym": synth.asymmetric_psf(), "full7": synth.full_support_psf()}[DTILE_CFGS[cfg][5] if len(DTILE_CFGS[cfg]) > 5 else "gauss"]
     O.set_threads(16)
     try:
         lrs, saas = [], []
