@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WL = {"c2": "c2:B=1024:f32", "c3_mono": "c3_mono:B=1:f32", "c3_mono_measured": "c3_mono_measured:B=1:f32", "c3_f4": "c3_f4:B=1:f32",
-      "c3_rgb": "c3_rgb:B=1:f32", "c3_rgb_measured": "c3_rgb_measured:B=1:f32", "c3_mono_f64": "c3_mono:B=1:f64", "c2_f64": "c2:B=1024:f64", "c2_measured": "c2_measured:B=1024:f32", "c3_rgb_f64": "c3_rgb:B=1:f64"}
+      "c3_rgb": "c3_rgb:B=1:f32", "c3_rgb_measured": "c3_rgb_measured:B=1:f32", "c3_mono_f64": "c3_mono:B=1:f64", "c2_f64": "c2:B=1024:f64", "c2_measured": "c2_measured:B=1024:f32", "c3_f4_measured": "c3_f4_measured:B=1:f32", "c3_rgb_f64": "c3_rgb:B=1:f64"}
 
 
 def one(pattern):
