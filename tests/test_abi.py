@@ -59,7 +59,7 @@ def test_exact_workspace_never_exceeds_the_shape_bound():
     from sr_mi355x import synth
     lib = _lib.load()
     dp = ctypes.POINTER(ctypes.c_double)
-    psfs = [synth.gaussian_psf(), synth.asymmetric_psf()]
+    psfs = [synth.gaussian_psf(), synth.asymmetric_psf(), synth.full_support_psf()]   # rank 1 / 5 x 5 core / full 7 x 7: three kernel forms
     worst = 0.0
     for f, shift_sets in ((2, (synth.NOMINAL_4, synth.NOMINAL_5, synth.MEASURED_4, synth.phase_shifts(2))),
                           (3, (synth.phase_shifts(3),)), (4, (synth.phase_shifts(4), synth.NOMINAL_4))):
@@ -73,7 +73,7 @@ def test_exact_workspace_never_exceeds_the_shape_bound():
                     for psf in psfs:
                         k = np.ascontiguousarray(psf)
                         for eb in (4, 8):
-                            for B in (1, 3):
+                            for B in (1, 3, 130):   # 130: past one chunk of the float64 strip kernels (128 patches)
                                 bound = lib.srx_ibp_workspace_bytes(eb, B, N, H // f, W // f, H, W, f, 0)
                                 need = lib.srx_ibp_workspace_bytes_for(eb, B, N, H // f, W // f, H, W, f, sh.ctypes.data_as(dp),
                                                                        k.ctypes.data_as(dp), 7, 7, 0)
