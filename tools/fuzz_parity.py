@@ -16,6 +16,15 @@ from sr_mi355x import synth  # noqa: E402
 from oracle import sr_oracle as O  # noqa: E402
 
 
+def _psf_variety(rng, full=True):
+    """Gaussian (rank 1) half of the time, else the 5 x 5-core asymmetric PSF (the reference's measured one looks like it) or, when the
+    kernel has that form, one with full 7 x 7 support."""
+    u = rng.uniform()
+    if u < 0.5:
+        return synth.gaussian_psf()
+    return synth.full_support_psf() if (full and u > 0.8) else synth.asymmetric_psf()
+
+
 def random_case(rng):
     f = int(rng.choice([2, 2, 3, 4, 4]))
     kind = rng.choice(["phase", "lattice", "free", "far", "patch", "frame0", "shifted", "window"], p=[0.2, 0.2, 0.14, 0.1, 0.1, 0.1, 0.1, 0.06])
@@ -33,19 +42,19 @@ def random_case(rng):
         N = int(rng.integers(2, len(grid) + 1))
         idx = rng.choice(len(grid), size=N, replace=False)
         H, W = 4 * int(rng.integers(64, 100)), 16 * int(rng.integers(12, 26))
-        return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], -(-H // f), -(-W // f), synth.gaussian_psf(), int(rng.integers(1, 4)), kind
+        return f, [(float(grid[i][0]), float(grid[i][1])) for i in idx], -(-H // f), -(-W // f), _psf_variety(rng), int(rng.integers(1, 4)), kind
     if kind == "shifted":    # k_ibp_bfwd / k_ibp_bbwd's domain: x2, per-frame fractions, |2 s| <= 4, Gaussian PSF, frames of one to several windows
         N = int(rng.integers(2, 9))
         shifts = [(float(rng.uniform(-1.99, 1.99)), float(rng.uniform(-1.99, 1.99))) for _ in range(N)]
         if rng.uniform() < 0.3:  # some frames on integer or half-pixel positions among them
             shifts[0] = (float(rng.integers(-3, 4)) / 2, float(rng.integers(-3, 4)) / 2)
-        return 2, shifts, int(rng.integers(16, 180)), int(rng.integers(16, 220)), synth.gaussian_psf(), int(rng.integers(1, 6)), kind
+        return 2, shifts, int(rng.integers(16, 180)), int(rng.integers(16, 220)), _psf_variety(rng), int(rng.integers(1, 6)), kind
     if kind == "frame0":     # k_ibp_ztile's domain: delta = 0 (integer HR shifts), at least 128 x 128 HR pixels, Gaussian PSF
         f = int(rng.choice([2, 3, 4]))
         lo = -min(3, f - 1)
         shifts = [(int(rng.integers(lo, 2)) / f, int(rng.integers(lo, 2)) / f) for _ in range(N)]
         h, w = int(rng.integers(-(-128 // f), 400 // f)), int(rng.integers(-(-128 // f), 400 // f))
-        return f, shifts, h, w, synth.gaussian_psf(), int(rng.integers(1, 6)), kind
+        return f, shifts, h, w, _psf_variety(rng), int(rng.integers(1, 6)), kind
     if kind == "phase":      # a subset of the full f x f phase grid (one common sub-pixel fraction)
         grid = synth.phase_shifts(f)
         idx = rng.choice(len(grid), size=min(N, len(grid)), replace=False)
