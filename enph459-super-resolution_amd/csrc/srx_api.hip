@@ -33,6 +33,15 @@ static const char *const g_kernel_names[KID_COUNT] = {
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
     "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile", "k_ibp_dtile", "k_ibp_ctile", "k_ibp_bfwd", "k_ibp_bbwd", "k_ibp_afwd", "k_ibp_abwd", "k_patch_build", "k_patch_flags", "k_atile_near", "k_ibp_sv", "k_ibp_sh", "k_saa_shift"};
 
+// One image plane (with SciPy's 12-sample pad on every side) and one item's N frames must stay below 2 GiB: the kernels index a plane with
+// 32-bit offsets and describe it to the memory unit as a buffer resource (32-bit byte count).  The batch is not limited (items are
+// re-based with 64-bit arithmetic); the reference's largest image is 3072 x 4096 (100 MB in float64).
+static inline bool plane_fits(size_t eb, int N, int h, int w, int H, int W)
+{
+    const size_t lim = (size_t)1 << 31;
+    return ((size_t)H + 2 * SRX_NPAD) * ((size_t)W + 2 * SRX_NPAD) * eb < lim && (size_t)(N > 0 ? N : 1) * h * w * eb < lim;
+}
+
 // ---------------------------------------------------------------------------------------
 // composed building blocks
 // ---------------------------------------------------------------------------------------
@@ -80,6 +89,8 @@ static int shift_cubic(const T *in, int B, int H, int W, double sy, double sx, T
 {
     if (!in || !out || B <= 0 || H <= 0 || W <= 0)
         return SRX_E_INVALID;
+    if (!plane_fits(sizeof(T), 1, H, W, H, W))
+        return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
     T *scr = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
@@ -114,6 +125,8 @@ static int zoom_cubic(const T *in, int B, int h, int w, int f, T *out, void *ws,
 {
     if (!in || !out || B <= 0 || h <= 0 || w <= 0 || f <= 0)
         return SRX_E_INVALID;
+    if ((size_t)h * f >= ((size_t)1 << 30) || (size_t)w * f >= ((size_t)1 << 30) || !plane_fits(sizeof(T), 1, h, w, h * f, w * f))
+        return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
     T *coef = ar.take<T>((size_t)B * h * w), *cscr = ar.take<T>((size_t)B * h * w);
     AxisTap<T> *ty = ar.take<AxisTap<T>>((size_t)h * f), *tx = ar.take<AxisTap<T>>((size_t)w * f);
@@ -134,6 +147,8 @@ static int forward_model(const T *hr, int B, int H, int W, const double *k, int 
 {
     if (!hr || !out || !k || B <= 0 || H <= 0 || W <= 0 || f <= 0)
         return SRX_E_INVALID;
+    if (!plane_fits(sizeof(T), 1, 1, 1, H, W))
+        return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
     T *b = ar.take<T>((size_t)B * H * W);
     T *pad = ar.take<T>((size_t)B * (H + 2 * SRX_NPAD) * (W + 2 * SRX_NPAD));
@@ -158,7 +173,7 @@ static int back_project(const T *err, int B, int eh, int ew, const double *k, in
 {
     if (!err || !out || !k || B <= 0 || eh <= 0 || ew <= 0 || H <= 0 || W <= 0 || f <= 0)
         return SRX_E_INVALID;
-    if (B > 65535)
+    if (B > 65535 || !plane_fits(sizeof(T), 1, eh, ew, H, W))
         return SRX_E_UNSUPPORTED;
     Arena ar(ws, wsb);
     T *up = ar.take<T>((size_t)B * H * W), *s2 = ar.take<T>((size_t)B * H * W);
@@ -309,7 +324,7 @@ static int ibp_dispatch(const T *lr, int B, int N, int h, int w, const double *s
 {
     if (!basic_ibp_args_ok(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, n_iter, hr))
         return SRX_E_INVALID;
-    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS)
+    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || !plane_fits(sizeof(T), N, h, w, H, W))
         return SRX_E_UNSUPPORTED;
     if (B > SRX_MAX_BATCH_PER_LAUNCH) {  // the workspace is sized for one chunk and reused (stream order)
         for (int b0 = 0; b0 < B; b0 += SRX_MAX_BATCH_PER_LAUNCH) {
@@ -346,7 +361,7 @@ static int saa_dispatch(const T *lr, int B, int N, int h, int w, const double *s
 {
     if (!lr || !sh || !out || B <= 0 || N <= 0 || h <= 0 || w <= 0 || f <= 0)
         return SRX_E_INVALID;
-    if (N > SRX_MAX_FRAMES)
+    if (N > SRX_MAX_FRAMES || (size_t)h * f >= ((size_t)1 << 30) || (size_t)w * f >= ((size_t)1 << 30) || !plane_fits(sizeof(T), N, h, w, h * f, w * f))
         return SRX_E_UNSUPPORTED;
     if ((long)B * N > SRX_MAX_BATCH_PER_LAUNCH) {
         const int step_b = SRX_MAX_BATCH_PER_LAUNCH / N > 0 ? SRX_MAX_BATCH_PER_LAUNCH / N : 1;
@@ -397,7 +412,7 @@ static int plan_create(const T *lr, int B, int N, int h, int w, const double *sh
 {
     if (!out || !basic_ibp_args_ok(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, f, 0, ws) || tr_lo < 0 || tr_hi > H || tr_lo > tr_hi)
         return SRX_E_INVALID;
-    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || B > SRX_MAX_BATCH_PER_LAUNCH)
+    if (N > SRX_MAX_FRAMES || kh * kw > SRX_MAX_KERNEL_TAPS || B > SRX_MAX_BATCH_PER_LAUNCH || !plane_fits(sizeof(T), N, h, w, H, W))
         return SRX_E_UNSUPPORTED;
     srx_plan_s *p = new srx_plan_s();
     p->eb = (int)sizeof(T), p->B = B, p->N = N, p->h = h, p->w = w, p->H = H, p->W = W, p->f = f, p->kh = kh, p->kw = kw, p->tr_lo = tr_lo, p->tr_hi = tr_hi;

@@ -47,7 +47,7 @@ static int blur(const T *img, int B, int H, int W, const double *kernel, int kh,
 {
     if (!img || !out || !kernel || B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0)
         return SRX_E_INVALID;
-    if (kh * kw > SRX_MAX_KERNEL_TAPS || B > 65535)
+    if (kh * kw > SRX_MAX_KERNEL_TAPS || B > 65535 || (size_t)H * W * sizeof(T) >= ((size_t)1 << 31))  // 32-bit offsets within a plane
         return SRX_E_UNSUPPORTED;
     KernelArg<T> ka;
     for (int i = 0; i < kh * kw; i++)

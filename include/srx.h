@@ -43,7 +43,8 @@ typedef void *srx_stream_t;
 typedef enum {
     SRX_OK = 0,
     SRX_E_INVALID = -1,     /* null pointer, non-positive size, bad factor */
-    SRX_E_UNSUPPORTED = -2, /* kernel larger than SRX_MAX_KERNEL_TAPS, N > SRX_MAX_FRAMES ... */
+    SRX_E_UNSUPPORTED = -2, /* kernel larger than SRX_MAX_KERNEL_TAPS, N > SRX_MAX_FRAMES, or one image plane (with its 12-sample pad) /
+                               one item's N frames of 2 GiB or more: planes are indexed with 32-bit offsets; the batch count is not limited */
     SRX_E_WORKSPACE = -3,   /* workspace pointer null or smaller than *_workspace_bytes() */
     SRX_E_HIP = -4          /* a HIP runtime call or kernel launch failed */
 } srx_status;

@@ -50,6 +50,31 @@ def test_argument_validation_without_gpu():
                            0) == _lib.E_INVALID
 
 
+def test_oversized_planes_are_refused_without_gpu():
+    """One image plane of 2 GiB or more (32-bit offsets inside a plane, include/srx.h) is SRX_E_UNSUPPORTED before any HIP call;
+    the pointers are never dereferenced."""
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    fake = ctypes.c_void_p(4096)
+    k = np.full((7, 7), 1.0 / 49)
+    sh = np.zeros((4, 2))
+    kp, sp = k.ctypes.data_as(dp), sh.ctypes.data_as(dp)
+    H = W = 1 << 15   # 32768 x 32768 float32 = 4 GiB, float64 = 8 GiB
+    assert lib.srx_blur_f32(fake, 1, H, W, kp, 7, 7, fake, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_shift_cubic_f64(fake, 1, H, W, 0.5, 0.5, fake, fake, 1 << 20, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_zoom_cubic_f32(fake, 1, H // 2, W // 2, 2, fake, fake, 1 << 20, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_forward_f32(fake, 1, H, W, kp, 7, 7, 0.5, 0.5, 2, fake, fake, 1 << 20, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_backproject_f32(fake, 1, H // 2, W // 2, kp, 7, 7, 0.5, 0.5, 2, H, W, fake, fake, 1 << 20, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_saa_f32(fake, 1, 4, H // 2, W // 2, sp, 2, fake, fake, 1 << 20, None, 0) == _lib.E_UNSUPPORTED
+    for fn in (lib.srx_ibp_f32, lib.srx_ibp_f64):
+        assert fn(fake, 1, 4, H // 2, W // 2, sp, kp, 7, 7, fake, H, W, 2, 1, 0.5, fake, None, fake, 1 << 20, None, 0) == _lib.E_UNSUPPORTED
+    # just past the limit (23200^2 x 4 B = 2.15 GB); the float64 planes of the reference's largest image are far below it
+    assert lib.srx_blur_f32(fake, 1, 23200, 23200, kp, 7, 7, fake, None) == _lib.E_UNSUPPORTED
+    assert lib.srx_ibp_workspace_bytes(8, 1, 5, 1536, 2048, 3072, 4096, 2, 0) > 0
+
+
 def test_exact_workspace_never_exceeds_the_shape_bound():
     """srx_ibp_workspace_bytes (shape only) must cover srx_ibp_workspace_bytes_for (shifts + PSF at hand) whatever
     implementation the call picks: a caller that sizes its arena once by the bound may not see SRX_E_WORKSPACE.
