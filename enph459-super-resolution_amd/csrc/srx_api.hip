@@ -215,7 +215,7 @@ static int saa_composed(const T *lr, int B, int N, int h, int w, const double *s
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     const size_t n = (size_t)B * H * W;
-    if (hipMemsetAsync(out, 0, n * sizeof(T), st) != hipSuccess)
+    if (fill_bytes(out, 0, n * sizeof(T), st) != hipSuccess)
         return SRX_E_HIP;
     for (int k = 0; k < N; k++) {
         SRX_TRY(zoom_into(lr + (size_t)k * h * w, (size_t)N * h * w, B, h, w, H, W, up, coef, cscr, zy, zx, st));
@@ -273,12 +273,12 @@ static int ibp_composed(const T *lr, int B, int N, int h, int w, const double *s
     }
     if (hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SRX_E_HIP;
-    if (errors && hipMemsetAsync(errors, 0, (size_t)B * n_iter * sizeof(double), st) != hipSuccess)
+    if (errors && fill_bytes(errors, 0, (size_t)B * n_iter * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
     const double scale = 1.0 / ((double)mh * (double)mw) / (double)N;
     for (int it = 0; it < n_iter; it++) {
         SRX_TRY(blur(hr, B, H, W, k, kh, kw, false, b, st));
-        if (hipMemsetAsync(corr, 0, P * sizeof(T), st) != hipSuccess)
+        if (fill_bytes(corr, 0, P * sizeof(T), st) != hipSuccess)
             return SRX_E_HIP;
         for (int q = 0; q < N; q++) {
             SRX_TRY(shift_sampled(b, B, H, W, 0, 0, f, sh, sw, sim, false, pad, scr, taps[4 * q], taps[4 * q + 1], true,

@@ -520,7 +520,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_atile_prep, dim3(cdiv(Wg, 64), Qn, B), dim3(64), 0, st, Mg, Cg, Hg, Wg, Qn, MCq);
     SRX_CHECK_LAUNCH();
-    if (hipMemsetAsync(G, 0, (size_t)B * Qn * Wg * 16, st) != hipSuccess)  // (the rows of the last quad past the plane are read, never written)
+    if (fill_bytes(G, 0, (size_t)B * Qn * Wg * 16, st) != hipSuccess)  // (the rows of the last quad past the plane are read, never written)
         return SRX_E_HIP;
     const dim3 gridf(A.nwx, A.nwy, B), gridb(cdiv(Wp, Geo<NBY, NBX>::OWBX), cdiv(Hp, Geo<NBY, NBX>::OWBY), B), blk(NBY * NBX * 64);
     for (int it = 0; it < n_iter; it++) {

@@ -191,6 +191,44 @@ Profiler &profiler();
             return _rc;                          \
     } while (0)
 
+// ---- fill: what the library uses instead of hipMemsetAsync ------------------------------------------------------------------
+// A call of the library is a chain of kernel launches (and a few device-to-device copies) on the caller's stream, so a caller may capture
+// it into a HIP graph (tools/dev/graph_replay.py, tests/test_gpu_graph.py).  hipMemsetAsync would be a memset NODE there; with a kernel of
+// our own a captured call is kernel nodes only.  (The frame kernels' two 50 MB plane memsets were where a replayed full-size
+// mono_cal_target step first came back wrong in round 4; the replays are exact with ROCm 7.2's graph packet path switched off and were
+// intermittently wrong with it on, memset nodes or not -- tests/test_gpu_graph.py says what is known.)  `bytes` and the address are
+// multiples of 4 (ints, floats, doubles).
+__global__ void __launch_bounds__(256) k_fill_words(unsigned *__restrict__ p, size_t nwords, unsigned v)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((size_t)p) & 15) == 0) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 *q = (u4 *)p;
+        const size_t n4 = nwords >> 2;
+        const u4 vv = {v, v, v, v};
+        for (size_t j = i; j < n4; j += stride)
+            q[j] = vv;
+        for (size_t j = (n4 << 2) + i; j < nwords; j += stride)
+            p[j] = v;
+        return;
+    }
+    for (; i < nwords; i += stride)
+        p[i] = v;
+}
+static inline hipError_t fill_bytes(void *p, int byte, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0)
+        return hipSuccess;
+    if ((((size_t)p) | bytes) & 3)
+        return hipErrorInvalidValue;
+    const unsigned b = (unsigned)byte & 0xffu, v = b * 0x01010101u;
+    const size_t nwords = bytes >> 2, nthreads = (nwords + 3) >> 2;
+    const size_t blocks = (nthreads + 255) / 256;
+    hipLaunchKernelGGL(k_fill_words, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, (unsigned *)p, nwords, v);
+    return hipGetLastError();
+}
+
 // ---- device helpers -------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T wave_sum(T v)
 {

@@ -578,11 +578,11 @@ static int iterate(const T *hr_init, T *hr, int B, int N, const mosaic::AxisPlan
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ctile_prep<T>, dim3(cdiv(WP, 256), HP / 2, B + 1), dim3(256), 0, st, Mg, Cg, B, H, W, HP, WP, za.nby, za.nbx, Mp, Cp);
     SRX_CHECK_LAUNCH();
-    if (hipMemsetAsync(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+    if (fill_bytes(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_ctile_pack<T>, dim3(cdiv(WP, 256), HP / 4, B), dim3(256), 0, st, Mp, Cp, HP, WP, CM4, cmok);
     SRX_CHECK_LAUNCH();
-    if (hipMemsetAsync(s0, 0, B * splane * sizeof(T), st) != hipSuccess || hipMemsetAsync(s1, 0, B * splane * sizeof(T), st) != hipSuccess)
+    if (fill_bytes(s0, 0, B * splane * sizeof(T), st) != hipSuccess || fill_bytes(s1, 0, B * splane * sizeof(T), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_ctile_copy_in<T>, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0);
     SRX_CHECK_LAUNCH();

@@ -909,7 +909,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     hipLaunchKernelGGL(patch::k_patch_params, dim3(1), dim3(1), 0, st, awp, aw);
     SRX_CHECK_LAUNCH();
     // ---- operand planes, near-band tables, state
-    if (hipMemsetAsync(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+    if (fill_bytes(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_dtile_prep, dim3(cdiv(W, 32), cdiv(H, 32), B + 1), dim3(32, 8), 0, st, Mg, Cg, B, H, W, da.y.nb, da.x.nb, Mt, Ct, Mt8, m8);
     SRX_CHECK_LAUNCH();

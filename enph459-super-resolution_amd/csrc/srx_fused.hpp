@@ -1429,7 +1429,7 @@ static int ibp(const T *lr, int B, int N, int h, int w, const double *sh, const 
     make_kernel7<T>(k, kh, kw, false, kc);
     make_kernel7<T>(k, kh, kw, true, kt);
     const size_t P = (size_t)B * H * W;
-    if (errors && hipMemsetAsync(errors, 0, (size_t)B * n_iter * sizeof(double), st) != hipSuccess)
+    if (errors && fill_bytes(errors, 0, (size_t)B * n_iter * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
     if (n_iter == 0 && hr != hr_init && hipMemcpyAsync(hr, hr_init, P * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SRX_E_HIP;

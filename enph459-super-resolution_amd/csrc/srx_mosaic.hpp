@@ -1300,7 +1300,7 @@ static int common_prep(Common<T> &c, Impl impl, const T *lr, int B, int N, int h
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_build_mtaps, dim3(cdiv(Wg, 64), N), dim3(64), 0, st, tabX, Wg, W, f, dx);
     SRX_CHECK_LAUNCH();
-    if (hipMemsetAsync(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
+    if (fill_bytes(Vtot, 0, (size_t)B * sizeof(double), st) != hipSuccess)
         return SRX_E_HIP;
     // (a batch of patches on a full phase grid: the patch path reads the LR frames itself, srx_patch.hpp's k_patch_build -- the M plane
     // of 1024 patches is 328 MB written here and read back once by k_patch_prep)

@@ -1427,7 +1427,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
     if (pa.nn > NN_PAD)
         return SRX_E_UNSUPPORTED;
     pa.c01 = c01_masks(py, px, N, f, pa.ry, pa.rx) ? 1 : 0;
-    if (hipMemsetAsync(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+    if (fill_bytes(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
     const bool own = builds_itself(py, px, N, f);  // (what mosaic::ibp asked before it decided not to build M / C / Mu)
     if (own) {

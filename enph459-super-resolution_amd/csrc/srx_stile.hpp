@@ -677,7 +677,7 @@ static int iterate(const T *hr_init, T *hr, int B, int N, int f, const mosaic::A
     if (pa.nn > NN_PAD)
         return SRX_E_UNSUPPORTED;
     pa.c01 = patch::c01_masks(py, px, N, f, pa.ry, pa.rx) ? 1 : 0;
-    if (hipMemsetAsync(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+    if (fill_bytes(m8, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_stile_prep<T>, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
     SRX_CHECK_LAUNCH();

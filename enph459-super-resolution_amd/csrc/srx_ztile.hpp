@@ -723,12 +723,12 @@ static int setup(State &zs, const float *hr_init, int B, int N, const mosaic::Ax
     }
     hipLaunchKernelGGL(k_ztile_prep, dim3(cdiv(WP, 32), cdiv(HP, 32), B + 1), dim3(32, 8), 0, st, Mg, Cg, B, H, W, HP, WP, za.nby, za.nbx, Mt, Ct);
     SRX_CHECK_LAUNCH();
-    if (hipMemsetAsync(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
+    if (fill_bytes(cmok, 0xff, (size_t)B * sizeof(int), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_ztile_pack, dim3(cdiv(HP, 256), WP / 2, B), dim3(256), 0, st, Mt, Ct, HP, WP, CM, cmok);
     SRX_CHECK_LAUNCH();
     // padded state planes: zero borders (and trash rows) once, then the image
-    if (hipMemsetAsync(s0, 0, B * splane * sizeof(float), st) != hipSuccess || hipMemsetAsync(s1, 0, B * splane * sizeof(float), st) != hipSuccess)
+    if (fill_bytes(s0, 0, B * splane * sizeof(float), st) != hipSuccess || fill_bytes(s1, 0, B * splane * sizeof(float), st) != hipSuccess)
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0, 0);
     SRX_CHECK_LAUNCH();

@@ -24,6 +24,17 @@
  *     enqueued on it; nothing synchronises the device.  No allocation happens inside a
  *     call: scratch comes from the caller's workspace (`*_workspace_bytes`, 256-B aligned
  *     device memory).  Inputs are never written; outputs never alias inputs unless stated.
+ *   - Streams and graphs: a call only queues kernels and device-to-device copies on `stream`
+ *     (every fill is a kernel, the host arrays are read before the call returns and travel as
+ *     kernel arguments or are expanded on the device), so it may be captured into a HIP graph
+ *     (hipStreamBeginCapture on `stream`) and replayed on new frames at the same addresses;
+ *     which implementation runs is decided from shapes, shifts and PSF, never from the samples
+ *     (what depends on them -- 8-bit operand packing, count masks -- is decided on the device).
+ *     tests/test_gpu_graph.py replays every implementation on new frames, bit for bit, with
+ *     DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: under ROCm 7.2's default graph path replays of short
+ *     chains were intermittently wrong from the second launch on (profiles/README.md), so check
+ *     before relying on it -- and replaying buys no time here (0.75x ... 1.02x of plain calls).
+ *     srx_profile_enable(1) records HIP events and should stay off during a capture.
  *   - Return value: SRX_OK (0) or a negative srx_status; srx_strerror() names it.  Like the
  *     reference's core, shape mismatches that the reference handles by crop/pad
  *     (run_sr.py:172-175, :199-201) are handled the same way, not reported.
