@@ -47,6 +47,12 @@ using patch::ZP;
 #ifndef SRX_BT_DBG
 #define SRX_BT_DBG 0  // timing ablations of a development build (results are wrong): 1 no residual stores, 2 no state stores, 4 no LR loads,
 #endif                // 8 no residual loads, 16 no state loads, 32 no transposes (registers copied)
+#ifndef SRX_BT_NBY
+#define SRX_BT_NBY 2  // window shape in 64 x 64 blocks = waves (ibp_t's comment has what other shapes measured)
+#endif
+#ifndef SRX_BT_NBX
+#define SRX_BT_NBX 2
+#endif
 #ifndef SRX_BT_MINB
 #define SRX_BT_MINB 2  // workgroups per CU the register allocation aims at
 #endif
@@ -1025,8 +1031,10 @@ static inline size_t ws_bytes(int B, int N, int h, int w, int H, int W)
 // Window shape: 2 x 2 waves (128 x 128 padded coordinates, 96 x 96 owned: 1.78x recompute), two or three workgroups per CU.  Measured
 // against 2 x 4 (128 x 256, 96 x 224 owned, 1.52x recompute, ONE workgroup of eight waves per CU) on 1536 x 2048: one frame 48.3
 // against 44.4 us per iteration, eight frames 211 against 185 -- eight waves that meet at every barrier wait for their slowest,
-// two independent workgroups fill each other's waits (srx_ztile.hpp found the same).  The shape is fixed, so a batch gives every
-// item the bits it gets alone.
+// two independent workgroups fill each other's waits (srx_ztile.hpp found the same).  Round 4, 2 x 3 and 3 x 2 waves (221 / 208 windows of
+// six waves: every window a compute unit of its own on one frame, tools/dev/bt_shape_ab.sh): one frame 2.087 / 2.16 against 2.06 ms per
+// step, eight frames 11.5 / 12.1 against 9.6, measured PSF 2.46 / 2.49 against 2.42 -- the six waves' barriers cost more than the idle
+// compute units.  The shape is fixed (SRX_BT_NBY x SRX_BT_NBX), so a batch gives every item the bits it gets alone.
 template <int NBY, int NBX>
 static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
                  int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
@@ -1125,7 +1133,7 @@ static int ibp_t(const float *lr, int B, int N, int h, int w, const double *sh, 
 static int ibp(const float *lr, int B, int N, int h, int w, const double *sh, const double *k, int kh, int kw, const float *hr_init, int H,
                int W, int n_iter, double step, float *hr, double *errors, void *ws, size_t wsb, hipStream_t st)
 {
-    return ibp_t<2, 2>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
+    return ibp_t<SRX_BT_NBY, SRX_BT_NBX>(lr, B, N, h, w, sh, k, kh, kw, hr_init, H, W, n_iter, step, hr, errors, ws, wsb, st);
 }
 
 }  // namespace btile
