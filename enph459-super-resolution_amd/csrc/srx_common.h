@@ -253,6 +253,16 @@ __device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
     bz = (int)(id / (gx * gy));
 }
 
+// the same for a one-dimensional list of n tiles: the tile that workgroup `orig` of the list takes
+__device__ __forceinline__ unsigned xcd_index(unsigned orig, unsigned n)
+{
+    const unsigned xcd = orig & 7u, q = n >> 3, r = n & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+#ifndef SRX_XCD_FRAME
+#define SRX_XCD_FRAME 1  // the register-resident frame / window kernels (k_ibp_ztile, k_ibp_ctile, k_ibp_dtile) take their tiles in that order too
+#endif
+
 // Diagnostic build only (-DSRX_STAMPS): s_memtime stamps at phase boundaries, thread 0 of every block, into a
 // buffer nothing else reads (tools/stamps.py reads it back).  No stamp executes in the normal build.
 #ifdef SRX_STAMPS

@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (SRX_XCD_FRAME)
+        xcd_block(tx, ty, b);
     const int H = ca.H, W = ca.W, HP = ca.HP, WP = ca.WP;
     const int pr0 = ty * VTY, pc0 = tx * VT;
     const bool top = ty == 0, left = tx == 0;

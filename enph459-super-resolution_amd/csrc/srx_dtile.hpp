@@ -353,12 +353,13 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), s = wave / NSX, u = wave - s * NSX;
     const int b = blockIdx.y;
+    const unsigned wid = SRX_XCD_FRAME ? xcd_index(blockIdx.x, gridDim.x) : blockIdx.x;  // windows that share halos (32 of 256 / 192) on one XCD's L2
     constexpr int m8 = M8 ? 1 : 0;
     TileD td;
     {
         typedef int i8 __attribute__((ext_vector_type(8)));
         i8 v;
-        const TileD *p = tb.tiles + blockIdx.x;
+        const TileD *p = tb.tiles + wid;
         asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
         td.oy = v[0], td.ox = v[1], td.y0 = v[2], td.y1 = v[3], td.x0 = v[4], td.x1 = v[5], td.ntab = v[6], td.flags = v[7];
     }
@@ -379,7 +380,7 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
     const float sn = da.sn;
     // The MSE trace of the PREVIOUS iteration: its windows' partial sums, added up in a fixed order by one window of this launch
     // (srx_ztile.hpp does the same); the last iteration's is k_dtile_trace's.
-    if (eprev && (int)blockIdx.x == min(da.tiles_x + 1, (int)gridDim.x - 1)) {
+    if (eprev && (int)wid == min(da.tiles_x + 1, (int)gridDim.x - 1)) {
         double sacc = 0.0;
         for (int i = tid0; i < (int)gridDim.x; i += NTHR)
             sacc += eprev[(size_t)b * gridDim.x + i];
@@ -696,7 +697,7 @@ __device__ __forceinline__ void dtile_body(float *lds, const float *__restrict__
 #pragma unroll
                 for (int i = 0; i < NW; i++)
                     t += part[i];
-                epart[(size_t)b * gridDim.x + blockIdx.x] = t;
+                epart[(size_t)b * gridDim.x + wid] = t;
             }
             const float gtop = exx ? gexx : r[0];
             const float gm1 = u == 0 ? gtop : Rlf[SLOT1 + 128 + lane];

@@ -356,7 +356,9 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     __shared__ float lds[LDS_WORDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave >> 2, u = wave & 3;
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (SRX_XCD_FRAME)
+        xcd_block(tx, ty, b);  // neighbouring tiles (12 shared rows of 64, 12 columns of 256) on one XCD's L2
     const int H = za.H, W = za.W, HP = za.HP, WP = za.WP;
     const int pr0 = ty * VTY, pc0 = tx * VT;  // padded coordinates of region (0, 0); natural = padded - 6
     float *Rown = lds + wave * patch::RW;
