@@ -15,7 +15,9 @@
 // (SRX_ZTILE_HOLD, the default): 216 registers, two tiles per CU, 180 MB, 43.9 / 268 us.  Taller tiles recompute less but run
 // slower: NSY = 2 (128 rows, 512 threads) 50 / 322 us, NSY = 4 (256 x 256, 1024 threads, one tile per CU) 64 / 446 us -- several
 // small independent workgroups per CU overlap one tile's memory phases with another's arithmetic, one lock-step workgroup
-// cannot.  Four tiles per CU (128 registers) spill 107 values: 61 / 452 us.
+// cannot.  Four tiles per CU (128 registers) spill 107 values: 61 / 452 us.  Round 4: the tiles are taken in XCD order (xcd_block: a tile's
+// vertical neighbours run on the same XCD, the 12 shared rows come from its L2): 160.7 -> 135.7 MB per iteration, 40.0 -> 39.4 us (the 7 x 7
+// form 46.5 -> 43.6); the re-reading form gains more from it (48.4 -> 42.2 / 263 us) and still loses to the held state (tools/dev/zhold_ab.sh).
 //
 // Near band (LR row / column 0 replicated into SciPy's pad: pixels g < -n_min, in the first rows / columns of the IMAGE): tiles
 // on the top / left image edge evaluate the per-pixel lists of k_build_near from two LDS strips of b, as k_ibp_patch does.
