@@ -259,6 +259,15 @@ __device__ __forceinline__ unsigned xcd_index(unsigned orig, unsigned n)
     const unsigned xcd = orig & 7u, q = n >> 3, r = n & 7u;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
+// a frame's tiles (blockIdx.x, blockIdx.y) re-numbered within the frame, the batch index (blockIdx.z) left alone: every frame of a batch is
+// spread over the eight XCDs in eight runs of consecutive tiles, as a single frame is (workgroups of one frame whose linear id agrees
+// mod 8 share an XCD whatever the frame's offset in the grid)
+__device__ __forceinline__ void xcd_block_2d(int &bx, int &by)
+{
+    const unsigned gx = gridDim.x, id = xcd_index(blockIdx.x + gx * blockIdx.y, gx * gridDim.y);
+    bx = (int)(id % gx);
+    by = (int)(id / gx);
+}
 #ifndef SRX_XCD_FRAME
 #define SRX_XCD_FRAME 1  // the register-resident frame / window kernels (k_ibp_ztile, k_ibp_ctile, k_ibp_dtile) take their tiles in that order too
 #endif

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256, 2)
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (SRX_XCD_FRAME)
-        xcd_block(tx, ty, b);
+        xcd_block_2d(tx, ty);
     const int H = ca.H, W = ca.W, HP = ca.HP, WP = ca.WP;
     const int pr0 = ty * VTY, pc0 = tx * VT;
     const bool top = ty == 0, left = tx == 0;

@@ -15,7 +15,7 @@
 // (SRX_ZTILE_HOLD, the default): 216 registers, two tiles per CU, 180 MB, 43.9 / 268 us.  Taller tiles recompute less but run
 // slower: NSY = 2 (128 rows, 512 threads) 50 / 322 us, NSY = 4 (256 x 256, 1024 threads, one tile per CU) 64 / 446 us -- several
 // small independent workgroups per CU overlap one tile's memory phases with another's arithmetic, one lock-step workgroup
-// cannot.  Four tiles per CU (128 registers) spill 107 values: 61 / 452 us.  Round 4: the tiles are taken in XCD order (xcd_block: a tile's
+// cannot.  Four tiles per CU (128 registers) spill 107 values: 61 / 452 us.  Round 4: the tiles are taken in XCD order (xcd_block_2d, frame by frame -- eight frames 257 us; re-numbered over the whole batch, one frame per XCD: 260 --: a tile's
 // vertical neighbours run on the same XCD, the 12 shared rows come from its L2): 160.7 -> 135.7 MB per iteration, 40.0 -> 39.4 us (the 7 x 7
 // form 46.5 -> 43.6); the re-reading form gains more from it (48.4 -> 42.2 / 263 us) and still loses to the held state (tools/dev/zhold_ab.sh).
 //
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256 * NSY, SRX_ZTILE_WPE)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = wave >> 2, u = wave & 3;
     int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (SRX_XCD_FRAME)
-        xcd_block(tx, ty, b);  // neighbouring tiles (12 shared rows of 64, 12 columns of 256) on one XCD's L2
+        xcd_block_2d(tx, ty);  // neighbouring tiles (12 shared rows of 64, 12 columns of 256) on one XCD's L2
     const int H = za.H, W = za.W, HP = za.HP, WP = za.WP;
     const int pr0 = ty * VTY, pc0 = tx * VT;  // padded coordinates of region (0, 0); natural = padded - 6
     float *Rown = lds + wave * patch::RW;
