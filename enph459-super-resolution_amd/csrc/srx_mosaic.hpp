@@ -923,6 +923,66 @@ __global__ void __launch_bounds__(256)
             dst[(size_t)r * Wc + lane] = reg[r * LD + lane];
 }
 
+// The same for float frames of exactly 64 x 64 samples (the C2 patches), lines in REGISTERS: a lane holds a column (64 coalesced loads
+// issued up front), filters it along the registers, the frame turns once through LDS (pitch 65), the lane filters a row, and the frame
+// turns back for coalesced stores -- 4 x 64 LDS accesses per lane and no recursion step waits for the LDS (k_prefilter_small walks its
+// lines IN the LDS: eight reads, eight dependent steps, eight writes at a time; 122 us for the 16 384 frames of a C2 batch, this one 90).
+// One wave per workgroup.  The arithmetic is k_prefilter_small's, step for step.
+template <typename T> __device__ __forceinline__ void prefilter_line64(T (&v)[64], int mode)
+{
+    const T z = pole<T>(), kq = (T)-6 * z;
+    static_assert(64 > Horizon<T>::n, "the cut boundary sum of causal_init (float)");
+    T zi = 1, acc = 0;
+#pragma unroll
+    for (int i = 0; i < Horizon<T>::n; i++) {
+        acc += zi * ((T)6 * v[i]);
+        zi *= z;
+    }
+    const T c0 = mode == MODE_MIRROR ? acc : (T)6 * v[0] + z * acc;
+    T prev = c0 / (T)6;
+    v[0] = -z * c0;
+#pragma unroll
+    for (int i = 1; i < 64; i++) {
+        prev = v[i] + z * prev;
+        v[i] = kq * prev;
+    }
+    T next = anticausal_init<T>((T)6 * prev, v[62] / -z, mode);
+    v[63] = next;
+#pragma unroll
+    for (int i = 62; i >= 0; i--) {
+        next = z * next + v[i];
+        v[i] = next;
+    }
+}
+__global__ void __launch_bounds__(64) k_prefilter_64(const float *__restrict__ src_, float *__restrict__ dst_, int mode)
+{
+    constexpr int LD = 65;
+    __shared__ float buf[64 * LD];
+    const int lane = threadIdx.x;
+    const float *src = src_ + (size_t)blockIdx.x * 4096;
+    float *dst = dst_ + (size_t)blockIdx.x * 4096;
+    float v[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++)
+        v[r] = src[r * 64 + lane];
+    prefilter_line64<float>(v, mode);  // axis 0: lane = column
+#pragma unroll
+    for (int r = 0; r < 64; r++)
+        buf[r * LD + lane] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+        v[c] = buf[lane * LD + c];
+    prefilter_line64<float>(v, mode);  // axis 1: lane = row
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+        buf[lane * LD + c] = v[c];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 64; r++)
+        dst[r * 64 + lane] = buf[r * LD + lane];
+}
+
 struct FrameOffsets {
     int oy[SRX_MAX_FRAMES], ox[SRX_MAX_FRAMES];
 };
@@ -1478,7 +1538,10 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
     T *Wpl = two_pass ? ar.take<T>((size_t)B * Hw * Ww) : nullptr;
     if (!ar.ok)
         return SRX_E_WORKSPACE;
-    if (h <= 64 && w <= 64) {
+    if (h == 64 && w == 64 && sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4)
+            SRX_LAUNCH(KID_PREFILTER_SMALL, k_prefilter_64, dim3(B * N), dim3(64), 0, st, lr, coef, (int)MODE_MIRROR);
+    } else if (h <= 64 && w <= 64) {
         SRX_LAUNCH(KID_PREFILTER_SMALL, k_prefilter_small<T>, dim3(cdiv(B * N, 4)), dim3(256), 0, st, lr, coef, B * N, h, w,
                    (int)MODE_MIRROR);
     } else {

@@ -280,27 +280,31 @@ __global__ void k_patch_maps(BuildMaps v, BuildMaps *dst)  // (a lane-indexed by
     for (int i = threadIdx.x; i < (int)(sizeof(BuildMaps) / 4); i += blockDim.x)
         d[i] = s[i];
 }
-// m8[b] (preset non-zero) cleared when a sample of patch b is not an integer in [0, 255].  grid (ceil(n / 4096), B), block 256
+// m8[b] (preset non-zero) cleared when a sample of patch b is not an integer in [0, 255].  grid (ceil(n / 8192), B), block 256; n is a
+// multiple of 4 (N frames of (256 / f)^2 samples).  All eight 16-byte loads of a lane are issued before the first test.  (63 us for the
+// 64 MB of a C2 batch, as with the round-3 form that tested sample by sample behind branches: ~1 TB/s on frames that are cold in the
+// Infinity Cache -- torch's own reductions read a WARM 64 MB buffer in 25 us, tools/dev/read_bw.py.)
 __global__ void __launch_bounds__(256) k_patch_flags(const float *__restrict__ lr, size_t n, int *__restrict__ m8)
 {
     const int b = blockIdx.y;
     const float4 *p = reinterpret_cast<const float4 *>(lr + (size_t)b * n);
-    bool ok = true;
+    const size_t n4 = n >> 2, i0 = (size_t)blockIdx.x * 2048 + threadIdx.x;
+    float4 v[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const size_t i = ((size_t)blockIdx.x * 4 + q) * 256 + threadIdx.x;
-        if (4 * i + 3 < n) {
-            const float4 v = p[i];
-            ok = ok && v.x == rintf(v.x) && v.x >= 0.f && v.x <= 255.f && v.y == rintf(v.y) && v.y >= 0.f && v.y <= 255.f &&
-                 v.z == rintf(v.z) && v.z >= 0.f && v.z <= 255.f && v.w == rintf(v.w) && v.w >= 0.f && v.w <= 255.f;
-        } else {
-            for (size_t j = 4 * i; j < n && j < 4 * i + 4; j++) {
-                const float x = lr[(size_t)b * n + j];
-                ok = ok && x == rintf(x) && x >= 0.f && x <= 255.f;
-            }
-        }
+    for (int q = 0; q < 8; q++) {
+        const size_t i = i0 + (size_t)q * 256;
+        v[q] = p[i < n4 ? i : 0];
     }
-    if (__syncthreads_or(!ok) && threadIdx.x == 0)
+    int bad = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float4 a = v[q];
+        const int ok = (int)(a.x == rintf(a.x)) & (int)(a.x >= 0.f) & (int)(a.x <= 255.f) & (int)(a.y == rintf(a.y)) & (int)(a.y >= 0.f) &
+                       (int)(a.y <= 255.f) & (int)(a.z == rintf(a.z)) & (int)(a.z >= 0.f) & (int)(a.z <= 255.f) & (int)(a.w == rintf(a.w)) &
+                       (int)(a.w >= 0.f) & (int)(a.w <= 255.f);
+        bad |= (i0 + (size_t)q * 256 < n4) & !ok;
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0)
         atomicAnd(&m8[b], 0);
 }
 // grid (PN / 16 bands, B), block 256: wave w takes rows w, w + 4, ... of the band, lane = column quad
@@ -1444,7 +1448,7 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         hipLaunchKernelGGL(k_patch_maps, dim3(1), dim3(256), 0, st, bm, maps);
         SRX_CHECK_LAUNCH();
         const size_t n = (size_t)N * src.h * src.w;
-        SRX_LAUNCH(KID_PATCH_FLAGS, k_patch_flags, dim3((unsigned)((n + 4095) / 4096), B), dim3(256), 0, st, src.lr, n, m8);
+        SRX_LAUNCH(KID_PATCH_FLAGS, k_patch_flags, dim3((unsigned)((n + 8191) / 8192), B), dim3(256), 0, st, src.lr, n, m8);
         SRX_LAUNCH(KID_PATCH_BUILD, k_patch_build, dim3(PN / 16, B), dim3(256), 0, st, src.lr, N, src.h, src.w, maps, m8, Mt, Mt8);
     } else {
         hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
