@@ -31,7 +31,7 @@ Profiler &profiler()
 static const char *const g_kernel_names[KID_COUNT] = {
     "k_blur_pad", "k_prefilter_axis0", "k_prefilter_axis1", "k_fwd_residual", "k_back_gather",
     "k_blurT_update", "k_interp", "k_fir_pad", "k_crop_div", "k_fwd_tile", "k_bwd_tile",
-    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile", "k_ibp_dtile", "k_ibp_ctile", "k_ibp_bfwd", "k_ibp_bbwd", "k_ibp_afwd", "k_ibp_abwd", "k_patch_build", "k_patch_flags", "k_atile_near", "k_ibp_sv", "k_ibp_sh", "k_saa_shift"};
+    "k_mosaic_build", "k_fwd_mosaic", "k_bwd_mosaic", "k_saa_tile", "k_prefilter_small", "k_prefilter_tile", "k_ibp_patch", "k_ibp_ztile", "k_ibp_dtile", "k_ibp_ctile", "k_ibp_bfwd", "k_ibp_bbwd", "k_ibp_afwd", "k_ibp_abwd", "k_patch_build", "k_patch_build_float", "k_atile_near", "k_ibp_sv", "k_ibp_sh", "k_saa_shift"};
 
 // One image plane (with SciPy's 12-sample pad on every side) and one item's N frames must stay below 2 GiB: the kernels index a plane with
 // 32-bit offsets and describe it to the memory unit as a buffer resource (32-bit byte count).  The batch is not limited (items are

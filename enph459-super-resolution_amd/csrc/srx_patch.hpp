@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(256)
 // row gy of M is the INTERLEAVE of one LR row of the f frames of its row class -- M[gy][gx] = lr[K[cy(gy)][cx(gx)]][iy(gy)][jx(gx)],
 // depth-to-space -- so the operand planes follow from the LR frames in one pass: a lane takes a column QUAD (for x4 the four frames of
 // the row class at one LR column: four coalesced 256-byte reads per wave and row), a 16-row band goes through LDS so that the
-// transposed planes leave in 256-byte runs.  The byte / float form is chosen BEFORE the build (k_patch_flags: all samples of the patch
-// are integers in [0, 255]) so that only the plane the iteration kernel will read is written: 64 KB instead of 320 KB per patch.
+// transposed planes leave in 256-byte runs.  The byte plane is written first and the float plane only for the patches that turn out to need it
+// (k_patch_build<0> / <1>: a sample that is not an integer in [0, 255]): 64 KB instead of 320 KB per patch of 8-bit frames.
 struct AxisMap {       // per natural coordinate g of a patch: the class of the frames that land there and the LR index they bring
     signed char cls[PN];   // -1: no frame (C = 0)
     unsigned char idx[PN];
@@ -280,41 +280,22 @@ __global__ void k_patch_maps(BuildMaps v, BuildMaps *dst)  // (a lane-indexed by
     for (int i = threadIdx.x; i < (int)(sizeof(BuildMaps) / 4); i += blockDim.x)
         d[i] = s[i];
 }
-// m8[b] (preset non-zero) cleared when a sample of patch b is not an integer in [0, 255].  grid (ceil(n / 8192), B), block 256; n is a
-// multiple of 4 (N frames of (256 / f)^2 samples).  All eight 16-byte loads of a lane are issued before the first test.  (63 us for the
-// 64 MB of a C2 batch, as with the round-3 form that tested sample by sample behind branches: ~1 TB/s on frames that are cold in the
-// Infinity Cache -- torch's own reductions read a WARM 64 MB buffer in 25 us, tools/dev/read_bw.py.)
-__global__ void __launch_bounds__(256) k_patch_flags(const float *__restrict__ lr, size_t n, int *__restrict__ m8)
-{
-    const int b = blockIdx.y;
-    const float4 *p = reinterpret_cast<const float4 *>(lr + (size_t)b * n);
-    const size_t n4 = n >> 2, i0 = (size_t)blockIdx.x * 2048 + threadIdx.x;
-    float4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const size_t i = i0 + (size_t)q * 256;
-        v[q] = p[i < n4 ? i : 0];
-    }
-    int bad = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const float4 a = v[q];
-        const int ok = (int)(a.x == rintf(a.x)) & (int)(a.x >= 0.f) & (int)(a.x <= 255.f) & (int)(a.y == rintf(a.y)) & (int)(a.y >= 0.f) &
-                       (int)(a.y <= 255.f) & (int)(a.z == rintf(a.z)) & (int)(a.z >= 0.f) & (int)(a.z <= 255.f) & (int)(a.w == rintf(a.w)) &
-                       (int)(a.w >= 0.f) & (int)(a.w <= 255.f);
-        bad |= (i0 + (size_t)q * 256 < n4) & !ok;
-    }
-    if (__syncthreads_or(bad) && threadIdx.x == 0)
-        atomicAnd(&m8[b], 0);
-}
-// grid (PN / 16 bands, B), block 256: wave w takes rows w, w + 4, ... of the band, lane = column quad
+// grid (PN / 16 bands, B), block 256: wave w takes rows w, w + 4, ... of the band, lane = column quad.
+// PASS 0 writes the BYTE plane of every patch and clears m8[b] (preset non-zero) when a sample it placed is not an integer in [0, 255];
+// PASS 1 writes the float plane of the patches so marked and returns at once for the others.  (Round 4's first form decided with a pass of
+// its own over the frames, k_patch_flags -- 63 us of a C2 step for a question this kernel answers on the way; frames of 8-bit integers,
+// the reference's data, now pay one empty launch instead, frames that are not pay the byte pass: +0.08 ms per 1024 patches.)
+template <int PASS>
 __global__ void __launch_bounds__(256)
-    k_patch_build(const float *__restrict__ lr, int N, int h, int w, const BuildMaps *__restrict__ maps, const int *__restrict__ m8,
+    k_patch_build(const float *__restrict__ lr, int N, int h, int w, const BuildMaps *__restrict__ maps, int *__restrict__ m8,
                   float *__restrict__ Mt, unsigned *__restrict__ Mt8)
 {
     __shared__ float4 tile[64][17];  // [column quad][row of the band] (+1: the write-out walks a quad's rows)
     const int b = blockIdx.y, gy0 = blockIdx.x * 16, cq = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool bytes = __builtin_amdgcn_readfirstlane(m8[b]) != 0;
+    constexpr bool bytes = PASS == 0;
+    if (PASS == 1 && __builtin_amdgcn_readfirstlane(m8[b]) != 0)
+        return;
+    int bad = 0;
     const float *src = lr + (size_t)b * N * h * w;
     int cx[4], jx[4];
 #pragma unroll
@@ -334,9 +315,19 @@ __global__ void __launch_bounds__(256)
                 if (cx[c] >= 0)
                     v[c] = src[((size_t)maps->frame[cy][cx[c]] * h + iy) * w + jx[c]];
         }
+        if (PASS == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)  // (the zeros of absent samples pass)
+                bad |= !((int)(v[c] == rintf(v[c])) & (int)(v[c] >= 0.f) & (int)(v[c] <= 255.f));
+        }
         tile[cq][r] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    __syncthreads();
+    if (PASS == 0) {
+        if (__syncthreads_or(bad) && threadIdx.x == 0)
+            atomicAnd(&m8[b], 0);
+    } else {
+        __syncthreads();
+    }
     if (bytes) {
         // Mt8[b][cq >> 2][gy][cq & 3]: one word per (quad, row); consecutive threads = the four quads of a group, then the rows
 #pragma unroll
@@ -1447,9 +1438,8 @@ static int iterate(const float *hr_init, float *hr, int B, int N, int f, const m
         bm.nby = pa.y.nb, bm.nbx = pa.x.nb;
         hipLaunchKernelGGL(k_patch_maps, dim3(1), dim3(256), 0, st, bm, maps);
         SRX_CHECK_LAUNCH();
-        const size_t n = (size_t)N * src.h * src.w;
-        SRX_LAUNCH(KID_PATCH_FLAGS, k_patch_flags, dim3((unsigned)((n + 8191) / 8192), B), dim3(256), 0, st, src.lr, n, m8);
-        SRX_LAUNCH(KID_PATCH_BUILD, k_patch_build, dim3(PN / 16, B), dim3(256), 0, st, src.lr, N, src.h, src.w, maps, m8, Mt, Mt8);
+        SRX_LAUNCH(KID_PATCH_BUILD, k_patch_build<0>, dim3(PN / 16, B), dim3(256), 0, st, src.lr, N, src.h, src.w, maps, m8, Mt, Mt8);
+        SRX_LAUNCH(KID_PATCH_FLAGS, k_patch_build<1>, dim3(PN / 16, B), dim3(256), 0, st, src.lr, N, src.h, src.w, maps, m8, Mt, Mt8);
     } else {
         hipLaunchKernelGGL(k_patch_prep, dim3(PN / 32, PN / 32, B + 1), dim3(32, 8), 0, st, Mg, Cg, B, Hg, Wg, pa.y.nb, pa.x.nb, Mt, Ct, Mt8, m8);
         SRX_CHECK_LAUNCH();

@@ -826,8 +826,8 @@ def test_strip_kernels_f64_chunks_and_traceless_calls():
 
 
 def test_patch_tables_from_the_lr_frames_equal_the_plane_route():
-    """Round 4: on a full phase grid the patch path builds its operand planes straight from the LR frames (k_patch_flags, k_patch_build,
-    k_patch_near_build) instead of through the batch's M / C / Mu planes (k_mosaic_build, k_patch_prep, k_patch_near_m: kept, on request,
+    """Round 4: on a full phase grid the patch path builds its operand planes straight from the LR frames (k_patch_build -- the byte plane of every patch, then the
+    float plane of those with a sample that is not an 8-bit integer --, k_patch_near_build) instead of through the batch's M / C / Mu planes (k_mosaic_build, k_patch_prep, k_patch_near_m: kept, on request,
     as the cross-check).  Same tables, so the same bits: integer frames (byte mosaic), non-integer frames (float mosaic), a mixed batch,
     a 3 x 4 sub-grid, x2."""
     S.set_precision("f32")

@@ -1,5 +1,5 @@
 """How fast does a short kernel read a buffer of a given size on this GPU?  (torch reductions / copies, HIP events; context for the 64 MB
-LR-frame passes of a C2 step -- k_patch_flags, k_patch_build, the 64 x 64 prefilter)"""
+LR-frame passes of a C2 step -- k_patch_build, the 64 x 64 prefilter)"""
 import torch
 for mb in (16, 64, 256, 1024):
     x = torch.rand(mb * 1024 * 1024 // 4, device="cuda")
