@@ -304,23 +304,30 @@ __global__ void __launch_bounds__(256)
         cx[c] = gx < maps->nbx ? -1 : maps->x.cls[gx];  // near-band columns: the kernel takes them from the near-band lists
         jx[c] = maps->x.idx[gx];
     }
+    // the frame of (row class, column class): 16 bytes, four scalar words (per lane and sample this was a dependent byte load from memory)
+    const int *fw = reinterpret_cast<const int *>(&maps->frame[0][0]);
+    const int fr0 = fw[0], fr1 = fw[1], fr2 = fw[2], fr3 = fw[3];
+    float v[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {  // all sixteen loads of a lane leave before the first one is looked at
+        const int gy = gy0 + wv + 4 * m;
+        const int cy = gy < maps->nby ? -1 : (int)maps->y.cls[gy], iy = maps->y.idx[gy];  // wave-uniform
+        const int fsel = cy == 0 ? fr0 : cy == 1 ? fr1 : cy == 2 ? fr2 : fr3;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            v[m][c] = 0.f;
+            if (cy >= 0 && cx[c] >= 0)
+                v[m][c] = src[((size_t)((fsel >> (8 * cx[c])) & 0xff) * h + iy) * w + jx[c]];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const int r = wv + 4 * m, gy = gy0 + r;
-        const int cy = gy < maps->nby ? -1 : (int)maps->y.cls[gy], iy = maps->y.idx[gy];  // wave-uniform
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cy >= 0) {
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (cx[c] >= 0)
-                    v[c] = src[((size_t)maps->frame[cy][cx[c]] * h + iy) * w + jx[c]];
-        }
         if (PASS == 0) {
 #pragma unroll
             for (int c = 0; c < 4; c++)  // (the zeros of absent samples pass)
-                bad |= !((int)(v[c] == rintf(v[c])) & (int)(v[c] >= 0.f) & (int)(v[c] <= 255.f));
+                bad |= !((int)(v[m][c] == rintf(v[m][c])) & (int)(v[m][c] >= 0.f) & (int)(v[m][c] <= 255.f));
         }
-        tile[cq][r] = make_float4(v[0], v[1], v[2], v[3]);
+        tile[cq][wv + 4 * m] = make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
     }
     if (PASS == 0) {
         if (__syncthreads_or(bad) && threadIdx.x == 0)
