@@ -1007,6 +1007,21 @@ template <typename T> static int prefilter2d_fast(T *a, T *scratch, int B, int H
     return prefilter2d(a, scratch, B, Hc, Wc, mode, st);
 }
 
+// The same out of place, src -> dst (the coefficients of a stack the caller may not write: the LR frames of shift_and_add).  The tile kernel
+// is out of place by nature, so this saves prefilter2d_fast's two copies of the stack (in, and back from the scratch plane).
+template <typename T> static int prefilter2d_from(const T *src, T *dst, T *scratch, int B, int Hc, int Wc, int mode, hipStream_t st)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (Hc >= 64 && Wc >= 64 && B <= 65535 && !(call_flags() & SRX_FLAG_DIAG_NO_PREFILTER_TILE)) {
+            SRX_LAUNCH(KID_PREFILTER_TILE, k_prefilter_tile<T>, dim3(cdiv(Wc, 64), cdiv(Hc, 64), B), dim3(256), 0, st, src, dst, Hc, Wc, mode);
+            return SRX_OK;
+        }
+    }
+    if (hipMemcpyAsync(dst, src, (size_t)B * Hc * Wc * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SRX_E_HIP;
+    return prefilter2d_fast(dst, scratch, B, Hc, Wc, mode, st);
+}
+
 // FWD: err[b,k,i,j] = lr[b,k,i,j] - (F_k P bpad)[f i, f j];  errors[b] += sum err^2 * scale.
 // One block per LR tile th x tw (f*th <= T_HR).  grid (ceil(w/tw), ceil(h/th), B), block 256.
 template <typename T>
@@ -1485,9 +1500,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
     if (!ar.ok)
         return SRX_E_WORKSPACE;
     // spline coefficients of every LR frame at once: [B*N, h, w], 'mirror' ends (scipy.ndimage.zoom)
-    if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return SRX_E_HIP;
-    SRX_TRY(prefilter2d_fast(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+    SRX_TRY(prefilter2d_from(lr, coef, cscr, B * N, h, w, MODE_MIRROR, st));
     const double zy_ = H > 1 ? (double)(h - 1) / (double)(H - 1) : 1.0;
     const double zx_ = W > 1 ? (double)(w - 1) / (double)(W - 1) : 1.0;
     SRX_TRY(build_taps(zy, H, h, TAP_ZOOM, 1, zy_, st));

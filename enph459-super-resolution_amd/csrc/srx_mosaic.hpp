@@ -1545,9 +1545,7 @@ static int saa(const T *lr, int B, int N, int h, int w, const double *sh, int f,
         SRX_LAUNCH(KID_PREFILTER_SMALL, k_prefilter_small<T>, dim3(cdiv(B * N, 4)), dim3(256), 0, st, lr, coef, B * N, h, w,
                    (int)MODE_MIRROR);
     } else {
-        if (hipMemcpyAsync(coef, lr, (size_t)B * N * h * w * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return SRX_E_HIP;
-        SRX_TRY(fused::prefilter2d_fast(coef, cscr, B * N, h, w, MODE_MIRROR, st));
+        SRX_TRY(fused::prefilter2d_from(lr, coef, cscr, B * N, h, w, MODE_MIRROR, st));
     }
     SRX_TRY(build_taps(zy, H, h, TAP_ZOOM, 1, H > 1 ? (double)(h - 1) / (double)(H - 1) : 1.0, st));
     SRX_TRY(build_taps(zx, W, w, TAP_ZOOM, 1, W > 1 ? (double)(w - 1) / (double)(W - 1) : 1.0, st));
