@@ -584,8 +584,8 @@ static int iterate(const T *hr_init, T *hr, int B, int N, const mosaic::AxisPlan
         return SRX_E_HIP;
     hipLaunchKernelGGL(k_ctile_pack<T>, dim3(cdiv(WP, 256), HP / 4, B), dim3(256), 0, st, Mp, Cp, HP, WP, CM4, cmok);
     SRX_CHECK_LAUNCH();
-    if (fill_bytes(s0, 0, B * splane * sizeof(T), st) != hipSuccess || fill_bytes(s1, 0, B * splane * sizeof(T), st) != hipSuccess)
-        return SRX_E_HIP;
+    hipLaunchKernelGGL(ztile::k_ztile_zero_border<T>, dim3(HP / 2 + 1, B), dim3(256), 0, st, s0, s1, H, W, HP, WP);  // (only what the image does not cover)
+    SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ctile_copy_in<T>, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0);
     SRX_CHECK_LAUNCH();
     if (NT > 0) {

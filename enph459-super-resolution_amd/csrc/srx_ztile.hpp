@@ -183,13 +183,15 @@ __global__ void __launch_bounds__(256) k_ztile_copy_out(const float *__restrict_
 // Zero what the image does not cover of both padded state planes: rows < 6 and >= H + 6 (the trash pair included), columns < 6 and
 // >= W + 6.  The image's own samples are copied in (plane 0) or written by the first iteration before anything reads them (plane 1), so
 // the two whole-plane fills of a 3072 x 4096 frame (2 x 50 MB, 27 us of a 3.5 ms call) were spent on values nobody saw.  grid (HP / 2 + 1, B)
-__global__ void __launch_bounds__(256) k_ztile_zero_border(float *__restrict__ s0, float *__restrict__ s1, int H, int W, int HP, int WP)
+template <typename T>
+__global__ void __launch_bounds__(256) k_ztile_zero_border(T *__restrict__ s0, T *__restrict__ s1, int H, int W, int HP, int WP)
 {
+    struct alignas(2 * sizeof(T)) T2 { T a, b; };
     const int pr = blockIdx.x, b = blockIdx.y, r0 = 2 * pr, r1 = r0 + 1;
     const size_t base = (size_t)b * (HP + 2) * WP + (size_t)pr * WP * 2;
-    float2 *p0 = reinterpret_cast<float2 *>(s0 + base), *p1 = reinterpret_cast<float2 *>(s1 + base);
+    T2 *p0 = reinterpret_cast<T2 *>(s0 + base), *p1 = reinterpret_cast<T2 *>(s1 + base);
     const bool in0 = r0 >= HALO && r0 < H + HALO, in1 = r1 >= HALO && r1 < H + HALO;
-    const float2 z2 = make_float2(0.f, 0.f);
+    const T2 z2 = {(T)0, (T)0};
     if (in0 && in1) {  // both rows of the pair inside the image: only the columns beside it
         const int nside = HALO + (WP - W - HALO);
         for (int i = threadIdx.x; i < nside; i += 256) {
@@ -204,8 +206,8 @@ __global__ void __launch_bounds__(256) k_ztile_zero_border(float *__restrict__ s
             p0[c] = z2, p1[c] = z2;
         } else {  // one row of the pair inside the image at a column inside it: the other row's element
             const int e = in0 ? 1 : 0;
-            reinterpret_cast<float *>(p0 + c)[e] = 0.f;
-            reinterpret_cast<float *>(p1 + c)[e] = 0.f;
+            reinterpret_cast<T *>(p0 + c)[e] = (T)0;
+            reinterpret_cast<T *>(p1 + c)[e] = (T)0;
         }
     }
 }
@@ -762,7 +764,7 @@ static int setup(State &zs, const float *hr_init, int B, int N, const mosaic::Ax
     hipLaunchKernelGGL(k_ztile_pack, dim3(cdiv(HP, 256), WP / 2, B), dim3(256), 0, st, Mt, Ct, HP, WP, CM, cmok);
     SRX_CHECK_LAUNCH();
     // padded state planes: zero borders (and trash rows) once, then the image
-    hipLaunchKernelGGL(k_ztile_zero_border, dim3(HP / 2 + 1, B), dim3(256), 0, st, s0, s1, H, W, HP, WP);
+    hipLaunchKernelGGL(k_ztile_zero_border<float>, dim3(HP / 2 + 1, B), dim3(256), 0, st, s0, s1, H, W, HP, WP);
     SRX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ztile_copy_in, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, hr_init, H, W, HP, WP, s0, 0);
     SRX_CHECK_LAUNCH();
